@@ -1,0 +1,157 @@
+/*
+ * mg_hip.h -- C ABI of libmg_hip.so, the MI355X (gfx950) implementation of the multigrid
+ * V-cycle kernels.
+ *
+ * Every entry point takes plain pointers and sizes.  Array pointers are DEVICE pointers to
+ * IEEE float64, row-major with a leading dimension `ld` (elements between consecutive rows,
+ * ld >= nx).  `stream` is a hipStream_t passed as void* (NULL = the null stream).  Unless a
+ * comment says otherwise a call only enqueues work on `stream` and returns.
+ * Return value: 0 on success, non-zero on error; mg_last_error() then describes it (the text
+ * is per host thread).  Nothing is thrown across this boundary.  Shapes are validated on the
+ * host before any launch, so a bad call is rejected instead of faulting the GPU.
+ *
+ * `nbatch`/`bstride`: the same operation is applied to nbatch independent grids whose arrays
+ * start bstride elements apart (every array argument of the call uses the same stride).
+ *
+ * File references below are into the reference checkout (Tugdual-G/multigrid): each entry
+ * point names the reference function it replaces.  Arithmetic follows the expression order of
+ * the reference and the library is built with -ffp-contract=off, so results are bit-identical
+ * to the reference's for the same inputs (mg_sor with MG_SOR_REDBLACK excepted, see there).
+ */
+#ifndef MG_HIP_H
+#define MG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+
+/* flags for the stencil entry points */
+#define MG_FLAG_FINEST 1 /* launch the instantiation named "...finest..." (profiler attribution only) */
+
+/* number of 8-byte slots a max-norm accumulator needs (see mg_residual) */
+#define MG_NORM_SLOTS 64
+
+int mg_abi_version(void);
+const char *mg_last_error(void);
+
+/* Tuning/testing knob: upper bound (1, 2 or 4 doubles) on the per-lane vector width the stencil
+ * kernels choose from the alignment of their arguments.  Results do not depend on it. */
+int mg_set_vector_width_cap(int cap);
+
+/*
+ * One Jacobi sweep, rows j0 <= j < j1 (1 <= j0, j1 <= ny-1), interior columns 1..nx-2:
+ *     x_out[j,i] = 0.25 * (x[j,i+1] + x[j,i-1] + x[j+1,i] + x[j-1,i] - h*h * b[j,i])
+ * Replaces smooth_sweep_jacobi, core/numba_modules.py:53-66, first loop.  The reference then
+ * copies the whole scratch array back (second loop); here the caller swaps x and x_out instead,
+ * which is equivalent when the boundary/halo cells of both arrays hold the same values.
+ * x_out must not alias x.
+ */
+int mg_jacobi(const double *b, const double *x, double *x_out, int64_t ny, int64_t nx, int64_t ld,
+              int64_t j0, int64_t j1, double h, int64_t nbatch, int64_t bstride, int flags, void *stream);
+
+/*
+ * The first Jacobi sweep from x = 0 without reading x:  x_out[j,i] = 0.25 * (0.0 - h*h * b[j,i]),
+ * the value the sweep above produces when x is all zeros (parallel_multigrid.py:276 zeroes x
+ * before smooth_parallel).  Interior cells of rows j0..j1-1 only.
+ */
+int mg_jacobi_from_zero(const double *b, double *x_out, int64_t ny, int64_t nx, int64_t ld, int64_t j0,
+                        int64_t j1, double h, int64_t nbatch, int64_t bstride, int flags, void *stream);
+
+/*
+ * Residual r = b - laplacian(x), rows j0 <= j < j1, interior columns, evaluated as
+ *     r[j,i] = b[j,i] - x[j,i-1]*hh - (x[j,i+1] + x[j-1,i] + x[j+1,i])*hh + (x[j,i]*hh)*4,  hh = 1/(h*h)
+ * Replaces residual, core/numba_modules.py:35-50.  Cells outside the range are not written.
+ * If norm_slots != NULL it must point to MG_NORM_SLOTS uint64 words (zeroed with
+ * mg_norm_reset before the call); the kernel max-accumulates the bit patterns of |r| of the
+ * cells it wrote, so that mg_norm_read returns np.amax(np.abs(r)) over them
+ * (core/parallel_multigrid.py:336), NaN included.
+ */
+int mg_residual(double *r, const double *x, const double *b, int64_t ny, int64_t nx, int64_t ld, int64_t j0,
+                int64_t j1, double h, uint64_t *norm_slots, int64_t nbatch, int64_t bstride, int flags,
+                void *stream);
+
+/* lplc[j,i] = (x[j,i-1] + x[j,i+1] + x[j-1,i] + x[j+1,i] - 4*x[j,i]) * (1/(h*h)) on the interior.
+ * Replaces laplacian, core/numba_modules.py:23-32. */
+int mg_laplacian(const double *x, double *lplc, int64_t ny, int64_t nx, int64_t ld, double h, void *stream);
+
+int mg_norm_reset(uint64_t *norm_slots, void *stream);
+/* Copies the slots to the host, WAITS for `stream`, writes the max to *out. */
+int mg_norm_read(const uint64_t *norm_slots, double *out, void *stream);
+/* np.amax(np.abs(a)) over a whole (ny x nx) array into norm_slots (reset first). */
+int mg_maxabs(const double *a, int64_t ny, int64_t nx, int64_t ld, uint64_t *norm_slots, void *stream);
+
+/*
+ * Full-weighting restriction, coarse rows J0 <= J < J1 (1 <= J0, J1 <= cny-1), coarse interior
+ * columns; the fine centre of coarse (J,I) is (2J+ofst_j, 2I+ofst_i):
+ *     crs[J,I] = f[c]/4 + (f[S]+f[N])*1/8 + ( (f[E]/8 + (f[SE]+f[NE])/16) + (f[W]/8 + (f[SW]+f[NW])/16) )
+ * Replaces coarse, core/numba_modules.py:132-160.  ofst_i, ofst_j in {0,-1}
+ * (core/parallel_multigrid.py:222-228).
+ */
+int mg_restrict(const double *fine, int64_t fny, int64_t fnx, int64_t fld, double *crs, int64_t cny,
+                int64_t cnx, int64_t cld, int64_t J0, int64_t J1, int64_t ofst_i, int64_t ofst_j,
+                int64_t nbatch, int64_t fbstride, int64_t cbstride, void *stream);
+
+/*
+ * Bilinear prolongation ADDED into the fine grid, fine rows t0 <= t < t1.  With (rt, rc) =
+ * (t - ofst_j, c - ofst_i), J = rt>>1, I = rc>>1, a fine cell is updated iff 1 <= rt <= 2*cny-3
+ * and 1 <= rc <= 2*cnx-3 (exactly the cells the reference's four passes touch):
+ *   rt even, rc even:  += crs[J,I]
+ *   rt odd,  rc odd :  += (crs[J+1,I+1] + crs[J+1,I] + crs[J,I+1] + crs[J,I]) / 4
+ *   rt even, rc odd :  += (crs[J,I] + crs[J,I+1]) / 2
+ *   rt odd,  rc even:  += (crs[J,I] + crs[J+1,I]) / 2
+ * Columns are further limited to c_lo <= c <= c_hi.  Replaces interpolate_add_to,
+ * core/numba_modules.py:163-180.
+ */
+int mg_prolong_add(const double *crs, int64_t cny, int64_t cnx, int64_t cld, double *fine, int64_t fny,
+                   int64_t fnx, int64_t fld, int64_t t0, int64_t t1, int64_t c_lo, int64_t c_hi,
+                   int64_t ofst_i, int64_t ofst_j, int64_t nbatch, int64_t cbstride, int64_t fbstride,
+                   void *stream);
+
+/*
+ * Coarse-grid smoother: `iterations` x (forward sweep [+ backward sweep]) of SOR with omega = 1.5,
+ *     x[j,i] = (1-w)*x[j,i] + (w/4)*(x[j,i+1] + x[j,i-1] + x[j+1,i] + x[j-1,i] - h*h*b[j,i]),
+ * in place, followed by the residual (as mg_residual) into r when r != NULL.
+ * Replaces smooth_altern (backward = 1), core/numba_modules.py:98-129, and smooth
+ * (backward = 0), :69-95.
+ *   MG_SOR_LEXICOGRAPHIC  the reference's row-major update order, executed as an anti-diagonal
+ *                         wavefront (cells with equal j+i are independent): bit-identical to the
+ *                         reference.  One workgroup per grid; the grid lives in LDS when
+ *                         ny*(nx rounded up to even) <= MG_SOR_LDS_DOUBLES, else in global memory.
+ *   MG_SOR_REDBLACK       colour = (j+i)&1; forward = colour 0 then 1, backward = 1 then 0.
+ *                         Not the reference's ordering: a different (weaker for few sweeps)
+ *                         smoother, offered for large coarse grids.
+ */
+#define MG_SOR_LEXICOGRAPHIC 0
+#define MG_SOR_REDBLACK 1
+#define MG_SOR_LDS_DOUBLES 20000
+int mg_sor(const double *b, double *x, double *r, int64_t ny, int64_t nx, int64_t ld, double h,
+           int64_t iterations, int backward, int ordering, int64_t nbatch, int64_t bstride, void *stream);
+
+/*
+ * dst[0:ny, 0:nx] = src[0:ny, 0:nx] with independent leading dimensions.  The data movement of
+ * split (core/numba_modules.py:10-20) and of the stitch in gather_blocks
+ * (core/parallel_multigrid.py:135-138): the caller offsets the pointers to select the block.
+ */
+int mg_copy2d(double *dst, int64_t dld, const double *src, int64_t sld, int64_t ny, int64_t nx, void *stream);
+
+/* split(A_in, A_out, rank), core/numba_modules.py:10-20: A_out (nout x nout) = corner `rank` of A_in. */
+int mg_split(const double *a_in, int64_t in_ny, int64_t in_nx, int64_t in_ld, double *a_out, int64_t nout,
+             int64_t out_ld, int64_t rank, void *stream);
+
+/*
+ * hipGraph capture of whatever is enqueued on `stream` between begin and end (the coarse tail
+ * of the V-cycle, or the whole cycle on one GPU).  mg_graph_end returns an executable graph.
+ */
+int mg_graph_begin(void *stream);
+int mg_graph_end(void *stream, void **graph_exec_out);
+int mg_graph_launch(void *graph_exec, void *stream);
+int mg_graph_destroy(void *graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MG_HIP_H */

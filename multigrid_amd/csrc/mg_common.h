@@ -1,0 +1,120 @@
+// Shared helpers of libmg_hip.so (gfx950 only): error reporting across the C ABI, argument
+// checks, whole-wave lane shifts, and the workgroup -> tile mapping.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mg_hip.h"
+
+typedef int64_t i64;
+typedef unsigned long long u64;
+
+void mg_set_error(const char *fmt, ...);
+
+#define MG_REQUIRE(cond, ...)        \
+    do {                             \
+        if (!(cond)) {               \
+            mg_set_error(__VA_ARGS__); \
+            return 1;                \
+        }                            \
+    } while (0)
+
+#define MG_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            mg_set_error("%s failed: %s", #call, hipGetErrorString(e_));          \
+            return 2;                                                             \
+        }                                                                         \
+    } while (0)
+
+#define MG_LAUNCH_CHECK(name)                                                     \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            mg_set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \
+            return 2;                                                             \
+        }                                                                         \
+    } while (0)
+
+static inline bool mg_aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+// ---- whole-wave shifts by one lane (wave = 64 lanes), DPP wave_shr:1 / wave_shl:1 ----------
+// wave_from_prev(v): lane l receives v of lane l-1 (lane 0 keeps its own v).
+// wave_from_next(v): lane l receives v of lane l+1 (lane 63 keeps its own v).
+// All 64 lanes must be active at the call.
+__device__ __forceinline__ double wave_from_prev(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_from_next(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- vector loads/stores of V consecutive doubles (V = 1, 2, 4) ----------------------------
+template <int V>
+__device__ __forceinline__ void ldv(double (&d)[V], const double *p)
+{
+    if constexpr (V == 1) {
+        d[0] = *p;
+    } else if constexpr (V == 2) {
+        double2 t = *reinterpret_cast<const double2 *>(p);
+        d[0] = t.x, d[1] = t.y;
+    } else {
+        double2 t0 = reinterpret_cast<const double2 *>(p)[0];
+        double2 t1 = reinterpret_cast<const double2 *>(p)[1];
+        d[0] = t0.x, d[1] = t0.y, d[2] = t1.x, d[3] = t1.y;
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv(double *p, const double (&d)[V])
+{
+    if constexpr (V == 1) {
+        *p = d[0];
+    } else if constexpr (V == 2) {
+        *reinterpret_cast<double2 *>(p) = make_double2(d[0], d[1]);
+    } else {
+        reinterpret_cast<double2 *>(p)[0] = make_double2(d[0], d[1]);
+        reinterpret_cast<double2 *>(p)[1] = make_double2(d[2], d[3]);
+    }
+}
+
+// ---- workgroup id -> (column block, row chunk) ----------------------------------------------
+// Workgroups b and b+8 are observed to share an XCD (and its L2).  The map gives each of the 8
+// groups a contiguous band of column blocks (or of row chunks), so that tiles that share edge
+// cache lines or halo rows are fetched through the same L2.  It is a bijection for every
+// (ncb, nrc); it affects speed only.
+__device__ __forceinline__ void mg_tile_of_block(int bid, int ncb, int nrc, int &cb, int &rc)
+{
+    if ((ncb & 7) == 0) {
+        int x = bid & 7, w = bid >> 3, cpx = ncb >> 3;
+        cb = x * cpx + (w % cpx);
+        rc = w / cpx;
+    } else if ((nrc & 7) == 0) {
+        int x = bid & 7, w = bid >> 3, rpx = nrc >> 3;
+        rc = x * rpx + (w / ncb);
+        cb = w % ncb;
+    } else {
+        cb = bid % ncb;
+        rc = bid / ncb;
+    }
+}
+
+// wave-level max of 64-bit unsigned keys, result valid in every lane
+__device__ __forceinline__ u64 wave_max_u64(u64 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        u64 o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}

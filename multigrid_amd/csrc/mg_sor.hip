@@ -1,0 +1,204 @@
+// Coarse-grid smoother of the V-cycle on gfx950: SOR (omega = 1.5), forward [+ backward] sweeps,
+// then the residual.
+//
+// MG_SOR_LEXICOGRAPHIC reproduces the reference's row-major Gauss-Seidel order exactly, in
+// parallel: when cell (j,i) is updated in a forward row-major sweep it sees the NEW values of
+// (j,i-1) and (j-1,i) and the OLD values of (j,i+1) and (j+1,i); cells on one anti-diagonal
+// d = j+i touch only diagonals d-1 and d+1, so a sweep is a wavefront over d = 2 .. ny+nx-4
+// with all cells of a diagonal updated together (backward sweep: d descending).  One workgroup
+// per grid, thread t owns row t+1 and walks along it one column per step, with one barrier per
+// diagonal.  The grid lives in LDS (row pitch rounded to an even number of doubles so that the
+// diagonal accesses of consecutive rows fall in different banks); the west neighbour and the
+// cell's own old value stay in registers, and b is prefetched 8 diagonals ahead so its
+// latency is not on the critical path.  The critical path is ny+nx dependent steps per sweep,
+// which no ordering-preserving algorithm can shorten; at ~0.15 us per step a 129 x 129 grid
+// takes ~40 us per sweep.
+// Grids too large for LDS use the same wavefront on global memory (correct but slow).
+//
+// MG_SOR_REDBLACK is the usual two-colour Gauss-Seidel, one launch per colour.
+#include "mg_common.h"
+
+#define SOR_PF 8 // prefetch distance for b, in diagonals
+
+template <bool LDS>
+__global__ __launch_bounds__(1024) void mg_sor_wavefront_kernel(const double *__restrict__ b, double *x,
+                                                                double *__restrict__ r, i64 ny, i64 nx, i64 ld,
+                                                                int ldl, double h2, int iterations, int backward,
+                                                                i64 bstride)
+{
+    extern __shared__ double sx[];
+    b += (i64)blockIdx.x * bstride;
+    x += (i64)blockIdx.x * bstride;
+    if (r) r += (i64)blockIdx.x * bstride;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double a = 1.5, alpha = 1 - a, beta = a / 4;
+
+    if constexpr (LDS) {
+        for (i64 idx = tid; idx < ny * nx; idx += nt) {
+            const i64 j = idx / nx, i = idx - j * nx;
+            sx[j * ldl + i] = x[j * ld + i];
+        }
+        __syncthreads();
+    }
+#define X(j, i) (LDS ? sx[(j) * (i64)ldl + (i)] : x[(j) * ld + (i)])
+#define XW(j, i, v)                         \
+    do {                                    \
+        if (LDS) sx[(j) * (i64)ldl + (i)] = (v); \
+        else x[(j) * ld + (i)] = (v);       \
+    } while (0)
+
+    const i64 dlo = 2, dhi = (ny - 2) + (nx - 2);
+    const bool one_row = (ny - 2) <= nt; // every thread owns at most one row: register pipeline
+    const i64 jrow = 1 + tid;
+    const bool have_row = jrow <= ny - 2;
+
+    for (int it = 0; it < iterations; ++it) {
+        for (int dir = 0; dir < (backward ? 2 : 1); ++dir) {
+            const i64 step = dir == 0 ? 1 : -1;
+            const i64 dstart = dir == 0 ? dlo : dhi;
+            const i64 nsteps = dhi - dlo + 1;
+            if (one_row) {
+                // Row-walking pipeline.  At step k the thread is at column i = dstart + step*k - jrow.
+                double breg[SOR_PF];
+                double self = 0, lat = 0; // own old value; value of the cell just left behind (new)
+                const double *brow = b + (have_row ? jrow : 1) * ld;
+#pragma unroll
+                for (int u = 0; u < SOR_PF; ++u) {
+                    const i64 i = dstart + step * u - jrow;
+                    breg[u] = (have_row && i >= 1 && i <= nx - 2) ? brow[i] : 0.0;
+                }
+                if (have_row) {
+                    const i64 ifirst = dir == 0 ? 1 : nx - 2;
+                    self = X(jrow, ifirst);
+                    lat = X(jrow, ifirst - step); // boundary cell next to the first column
+                }
+                for (i64 k0 = 0; k0 < nsteps; k0 += SOR_PF) {
+#pragma unroll
+                    for (int u = 0; u < SOR_PF; ++u) {
+                        const i64 k = k0 + u;
+                        const i64 i = dstart + step * k - jrow;
+                        const bool act = have_row && k < nsteps && i >= 1 && i <= nx - 2;
+                        const double bv = breg[u];
+                        const i64 ip = i + step * SOR_PF;
+                        breg[u] = (have_row && ip >= 1 && ip <= nx - 2) ? brow[ip] : 0.0;
+                        if (act) {
+                            const double ahead = X(jrow, i + step);   // (j, i+1) forward / (j, i-1) backward: old
+                            const double below = X(jrow + 1, i);
+                            const double above = X(jrow - 1, i);
+                            const double E = dir == 0 ? ahead : lat;
+                            const double W = dir == 0 ? lat : ahead;
+                            const double v = alpha * self + beta * (E + W + below + above - h2 * bv);
+                            XW(jrow, i, v);
+                            lat = v;
+                            self = ahead;
+                        }
+                        if (k < nsteps) {
+                            if constexpr (LDS) {
+                                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            } else {
+                                __syncthreads();
+                            }
+                        }
+                    }
+                }
+            } else {
+                for (i64 k = 0; k < nsteps; ++k) {
+                    const i64 d = dstart + step * k;
+                    for (i64 j = 1 + tid; j <= ny - 2; j += nt) {
+                        const i64 i = d - j;
+                        if (i >= 1 && i <= nx - 2) {
+                            const double v = alpha * X(j, i) +
+                                             beta * (X(j, i + 1) + X(j, i - 1) + X(j + 1, i) + X(j - 1, i) -
+                                                     h2 * b[j * ld + i]);
+                            XW(j, i, v);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+
+    if constexpr (LDS) {
+        __syncthreads();
+        const double hh = 1 / h2;
+        for (i64 idx = tid; idx < ny * nx; idx += nt) {
+            const i64 j = idx / nx, i = idx - j * nx;
+            const double c = sx[j * ldl + i];
+            x[j * ld + i] = c;
+            if (r && j >= 1 && j <= ny - 2 && i >= 1 && i <= nx - 2) {
+                const double left = sx[j * ldl + i - 1] * hh, cent = c * hh;
+                r[j * ld + i] = b[j * ld + i] - left -
+                                (sx[j * ldl + i + 1] + sx[(j - 1) * ldl + i] + sx[(j + 1) * ldl + i]) * hh + cent * 4;
+            }
+        }
+    }
+#undef X
+#undef XW
+}
+
+__global__ __launch_bounds__(256) void mg_sor_rb_kernel(const double *__restrict__ b, double *x, i64 ny, i64 nx, i64 ld,
+                                                        double h2, int colour, i64 bstride)
+{
+    b += (i64)blockIdx.z * bstride;
+    x += (i64)blockIdx.z * bstride;
+    const double a = 1.5, alpha = 1 - a, beta = a / 4;
+    for (i64 j = 1 + blockIdx.y; j <= ny - 2; j += gridDim.y) {
+        const i64 i0 = 1 + ((colour + j + 1) & 1);
+        for (i64 i = i0 + 2 * ((i64)blockIdx.x * 256 + threadIdx.x); i <= nx - 2; i += 2 * (i64)gridDim.x * 256) {
+            double *p = x + j * ld + i;
+            *p = alpha * *p + beta * (p[1] + p[-1] + p[ld] + p[-ld] - h2 * b[j * ld + i]);
+        }
+    }
+}
+
+extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64 ld, double h, i64 iterations,
+                      int backward, int ordering, i64 nbatch, i64 bstride, void *stream)
+{
+    MG_REQUIRE(b && x, "mg_sor: null array");
+    MG_REQUIRE(ny >= 3 && nx >= 3 && ld >= nx, "mg_sor: bad shape %lld x %lld (ld %lld)", (long long)ny, (long long)nx,
+               (long long)ld);
+    MG_REQUIRE(iterations >= 0 && iterations < (1 << 20), "mg_sor: bad iteration count");
+    MG_REQUIRE(nbatch >= 1 && nbatch <= 65535, "mg_sor: nbatch %lld outside 1..65535", (long long)nbatch);
+    MG_REQUIRE(nbatch == 1 || bstride >= ny * ld, "mg_sor: bstride overlaps consecutive grids");
+    MG_REQUIRE(ordering == MG_SOR_LEXICOGRAPHIC || ordering == MG_SOR_REDBLACK, "mg_sor: unknown ordering %d", ordering);
+    MG_REQUIRE(nx < ((i64)1 << 30) && ny < ((i64)1 << 30), "mg_sor: grid side too large");
+    hipStream_t st = (hipStream_t)stream;
+    const double h2 = h * h;
+    if (ordering == MG_SOR_LEXICOGRAPHIC) {
+        const int ldl = (int)((nx + 1) & ~(i64)1);
+        const bool lds = ny * (i64)ldl <= MG_SOR_LDS_DOUBLES;
+        int nt = (int)(((ny - 2) + 63) / 64 * 64);
+        if (nt > 1024) nt = 1024;
+        if (lds) {
+            const size_t bytes = (size_t)ny * ldl * sizeof(double);
+            static bool attr_set = false;
+            if (!attr_set) {
+                MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wavefront_kernel<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           MG_SOR_LDS_DOUBLES * (int)sizeof(double)));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(mg_sor_wavefront_kernel<true>, dim3((unsigned)nbatch), dim3(nt), bytes, st, b, x, r, ny,
+                               nx, ld, ldl, h2, (int)iterations, backward, bstride);
+            MG_LAUNCH_CHECK("mg_sor (LDS wavefront)");
+            return 0;
+        }
+        hipLaunchKernelGGL(mg_sor_wavefront_kernel<false>, dim3((unsigned)nbatch), dim3(nt), 0, st, b, x, nullptr, ny,
+                           nx, ld, ldl, h2, (int)iterations, backward, bstride);
+        MG_LAUNCH_CHECK("mg_sor (global wavefront)");
+    } else {
+        unsigned gx = (unsigned)(((nx - 2 + 1) / 2 + 255) / 256);
+        if (gx > 64) gx = 64;
+        unsigned gy = (unsigned)(ny - 2 < 2048 ? ny - 2 : 2048);
+        dim3 grid(gx, gy, (unsigned)nbatch);
+        for (i64 it = 0; it < iterations; ++it)
+            for (int p = 0; p < (backward ? 4 : 2); ++p) {
+                const int colour = (p == 0 || p == 3) ? 0 : 1;
+                hipLaunchKernelGGL(mg_sor_rb_kernel, grid, dim3(256), 0, st, b, x, ny, nx, ld, h2, colour, bstride);
+                MG_LAUNCH_CHECK("mg_sor (red-black)");
+            }
+    }
+    if (r) return mg_residual(r, x, b, ny, nx, ld, 1, ny - 1, h, nullptr, nbatch, bstride, 0, stream);
+    return 0;
+}

@@ -55,7 +55,7 @@ def lib():
         L.orc_blocks_array.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(_i64)]
         L.orc_blocks_array.restype = C.POINTER(C.c_double)
         L.orc_blocks_set_verbose.argtypes = [C.c_void_p, C.c_int]
-        L.orc_blocks_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_blocks_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_blocks_solve.restype = C.c_int
         L.orc_global_create.argtypes = [_i64, _i64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
         L.orc_global_create.restype = C.c_void_p
@@ -157,7 +157,10 @@ class BlockSolver:
         err = np.zeros(4)
         self.err_hist = np.zeros((4, 100))
         self.r_hist = np.zeros((4, 100))
-        self.it = lib().orc_blocks_solve(self._h, err.ctypes.data, self.err_hist.ctypes.data, self.r_hist.ctypes.data)
+        self.interior_hist = np.zeros(100)
+        self.it = lib().orc_blocks_solve(self._h, err.ctypes.data, self.err_hist.ctypes.data, self.r_hist.ctypes.data,
+                                         self.interior_hist.ctypes.data)
+        self.interior_hist = self.interior_hist[: self.it]
         self.err_hist = self.err_hist[:, : self.it]
         self.r_hist = self.r_hist[:, : self.it]
         return err

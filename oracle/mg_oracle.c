@@ -380,9 +380,22 @@ static const int OFS_J[NRANK] = {0, 0, -1, -1};
  * Multigrid.solve(), core/parallel_multigrid.py:232-348.
  * err_out[4]: the value each rank returns.  err_hist[4*100]: np.amax(|r_sb[0]|) of each rank at
  * each convergence vote (:336).  r_hist[4*100]: max|r_sb[0]| of each rank right after the halo
- * exchange of r at the top of each cycle (:272).  Returns self.it.
+ * exchange of r at the top of each cycle (:272).  int_hist[100]: max over the four ranks of
+ * max|r_sb[0]| over the block INTERIORS only (no halo line), i.e. the max-norm of the residual
+ * on the whole grid, which is what a solver without stale halo copies measures.
+ * Any of the three history pointers may be NULL.  Returns self.it.
  */
-int orc_blocks_solve(void *hd, double *err_out, double *err_hist, double *r_hist)
+static double interior_maxabs(const double *a, i64 m)
+{
+    double v = 0;
+    for (i64 j = 1; j < m - 1; j++)
+        for (i64 i = 1; i < m - 1; i++)
+            if (fabs(a[j * m + i]) > v)
+                v = fabs(a[j * m + i]);
+    return v;
+}
+
+int orc_blocks_solve(void *hd, double *err_out, double *err_hist, double *r_hist, double *int_hist)
 {
     blocks_t *s = (blocks_t *)hd;
     const int n = s->n, n_para = s->n_para, n1 = 3, n2 = 6, L = s->nwl;
@@ -448,6 +461,14 @@ int orc_blocks_solve(void *hd, double *err_out, double *err_hist, double *r_hist
         }
         /* convergence vote (:336-345) */
         status = 0;
+        if (int_hist) {
+            int_hist[s->it] = 0;
+            for (int rk = 0; rk < NRANK; rk++) {
+                double v = interior_maxabs(s->r_sb[rk][0], s->sb_n[0]);
+                if (v > int_hist[s->it])
+                    int_hist[s->it] = v;
+            }
+        }
         for (int rk = 0; rk < NRANK; rk++) {
             err[rk] = orc_maxabs(s->r_sb[rk][0], s->sb_n[0] * s->sb_n[0]);
             if (err_hist)

@@ -1,0 +1,375 @@
+"""HIP kernels (through the C ABI) against the golden vectors and against the CPU oracle.
+
+Bit-exact (np.array_equal) everywhere: the kernels keep the reference's expression order and are
+built without multiply-add fusion.  Marked gpu: runs on the MI355X box only.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+K = np.load(os.path.join(GOLDEN, "kernels.npz"))
+META = json.loads(str(K["meta"]))
+
+
+def cases(kernel):
+    return [m for m in META if m["kernel"] == kernel]
+
+
+@pytest.fixture(scope="module")
+def mm():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from multigrid_amd import multigrid_module
+    return multigrid_module
+
+
+@pytest.fixture(scope="module")
+def L():
+    from multigrid_amd import _lib
+    return _lib
+
+
+def padded(a, ld=None, device="cuda"):
+    """Device copy of `a` inside a wider allocation: a view with row stride `ld` (16-element
+    multiple by default, which makes the widest vector path eligible)."""
+    import torch
+    ny, nx = a.shape
+    if ld is None:
+        ld = (nx + 15) // 16 * 16
+    buf = torch.zeros((ny, ld), dtype=torch.float64, device=device)
+    buf[:, :nx] = torch.from_numpy(np.ascontiguousarray(a))
+    return buf[:, :nx]
+
+
+# ------------------------------------------------------------------ golden vectors, numpy in/out
+
+
+@pytest.mark.parametrize("m", cases("residual"), ids=lambda m: f"residual{m['id']}")
+def test_golden_residual(mm, m):
+    k = m["id"]
+    r = K[f"residual{k}_r0"].copy()
+    mm.residual(r, K[f"residual{k}_a"], K[f"residual{k}_b"], m["h"])
+    assert np.array_equal(r, K[f"residual{k}_r"])
+
+
+@pytest.mark.parametrize("m", cases("laplacian"), ids=lambda m: f"laplacian{m['id']}")
+def test_golden_laplacian(mm, m):
+    k = m["id"]
+    l = K[f"laplacian{k}_l0"].copy()
+    mm.laplacian(K[f"laplacian{k}_a"], l, m["h"])
+    assert np.array_equal(l, K[f"laplacian{k}_l"])
+
+
+@pytest.mark.parametrize("m", cases("smooth_sweep_jacobi"), ids=lambda m: f"jacobi{m['id']}")
+def test_golden_jacobi(mm, m):
+    k = m["id"]
+    a, t = K[f"jacobi{k}_a0"].copy(), K[f"jacobi{k}_t0"].copy()
+    mm.smooth_sweep_jacobi(K[f"jacobi{k}_b"], a, t, m["h"])
+    assert np.array_equal(a, K[f"jacobi{k}_a"])
+    assert np.array_equal(t, K[f"jacobi{k}_t"])
+
+
+@pytest.mark.parametrize("m", cases("smooth") + cases("smooth_altern"), ids=lambda m: f"{m['kernel']}{m['id']}")
+def test_golden_sor(mm, m):
+    k = m["id"]
+    x, r = K[f"sor{k}_x0"].copy(), K[f"sor{k}_r0"].copy()
+    getattr(mm, m["kernel"])(K[f"sor{k}_b"], x, m["h"], r, m["iterations"])
+    assert np.array_equal(x, K[f"sor{k}_x"])
+    assert np.array_equal(r, K[f"sor{k}_r"])
+
+
+@pytest.mark.parametrize("m", cases("coarse"), ids=lambda m: f"coarse{m['id']}")
+def test_golden_coarse(mm, m):
+    k = m["id"]
+    c = K[f"coarse{k}_c0"].copy()
+    mm.coarse(K[f"coarse{k}_f"], c, m["ofst_i"], m["ofst_j"])
+    assert np.array_equal(c, K[f"coarse{k}_c"])
+
+
+@pytest.mark.parametrize("m", cases("interpolate_add_to"), ids=lambda m: f"interp{m['id']}")
+def test_golden_interpolate(mm, m):
+    k = m["id"]
+    f = K[f"interp{k}_f0"].copy()
+    mm.interpolate_add_to(K[f"interp{k}_c"], f, m["ofst_i"], m["ofst_j"])
+    assert np.array_equal(f, K[f"interp{k}_f"])
+
+
+@pytest.mark.parametrize("m", cases("split"), ids=lambda m: f"split{m['id']}")
+def test_golden_split(mm, m):
+    k = m["id"]
+    o = np.zeros_like(K[f"split{k}_out"])
+    mm.split(K[f"split{k}_in"], o, m["rank"])
+    assert np.array_equal(o, K[f"split{k}_out"])
+
+
+# ------------------------------------------------------------------ oracle, device tensors, all vector widths
+
+SHAPES = [(3, 3), (5, 9), (33, 33), (130, 130), (257, 513), (514, 1030), (100, 2051)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=str)
+@pytest.mark.parametrize("cap", [1, 2, 4])
+def test_stencils_vs_oracle(mm, L, shape, cap):
+    rng = np.random.default_rng(hash(shape) % 1000 + cap)
+    a, b = rng.standard_normal(shape), rng.standard_normal(shape)
+    r0, t0 = rng.standard_normal(shape), None
+    h = 0.3
+    L.check(L.lib().mg_set_vector_width_cap(cap))
+    try:
+        # residual
+        r_ref = r0.copy()
+        oracle.residual(r_ref, a, b, h)
+        da, db, dr = padded(a), padded(b), padded(r0)
+        mm.residual(dr, da, db, h)
+        assert np.array_equal(dr.cpu().numpy(), r_ref)
+        # jacobi (module semantics: a_temp pre-filled with a)
+        a_ref, t_ref = a.copy(), a.copy()
+        oracle.smooth_sweep_jacobi(b, a_ref, t_ref, h)
+        da, dt = padded(a), padded(a)
+        mm.smooth_sweep_jacobi(db, da, dt, h)
+        assert np.array_equal(da.cpu().numpy(), a_ref)
+        assert np.array_equal(dt.cpu().numpy(), t_ref)
+        # laplacian
+        l_ref = r0.copy()
+        oracle.laplacian(a, l_ref, h)
+        dl = padded(r0)
+        mm.laplacian(padded(a), dl, h)
+        assert np.array_equal(dl.cpu().numpy(), l_ref)
+    finally:
+        L.check(L.lib().mg_set_vector_width_cap(4))
+
+
+def test_jacobi_row_range_and_from_zero(L):
+    """Row-range launches touch only their rows; the from-zero sweep equals a sweep on x = 0."""
+    import torch
+    rng = np.random.default_rng(5)
+    ny, nx = 70, 300
+    a, b = rng.standard_normal((ny, nx)), rng.standard_normal((ny, nx))
+    h = 0.7
+    ref, t = a.copy(), a.copy()
+    oracle.smooth_sweep_jacobi(b, ref, t, h)
+    da, db = padded(a), padded(b)
+    out = padded(np.full((ny, nx), 7.0))
+    ld = out.stride(0)
+    st = torch.cuda.current_stream().cuda_stream
+    lib = L.lib()
+    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 10, 33, h, 1, 0, 0, st))
+    o = out.cpu().numpy()
+    assert np.array_equal(o[10:33, 1:-1], ref[10:33, 1:-1])
+    o[10:33, 1:-1] = 7.0
+    assert np.all(o == 7.0)
+    # two launches covering disjoint row ranges == one full sweep
+    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 1, 10, h, 1, 0, 0, st))
+    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 10, ny - 1, h, 1, 0, 0, st))
+    assert np.array_equal(out.cpu().numpy()[1:-1, 1:-1], ref[1:-1, 1:-1])
+    # from zero
+    z, tz = np.zeros((ny, nx)), np.zeros((ny, nx))
+    oracle.smooth_sweep_jacobi(b, z, tz, h)
+    out2 = padded(np.zeros((ny, nx)))
+    L.check(lib.mg_jacobi_from_zero(db.data_ptr(), out2.data_ptr(), ny, nx, ld, 1, ny - 1, h, 1, 0, 0, st))
+    got = out2.cpu().numpy()
+    assert np.array_equal(got, z)
+    assert np.array_equal(np.signbit(got), np.signbit(z))
+
+
+def test_residual_norm(L):
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(9)
+    ny, nx = 515, 1027
+    a, b = rng.standard_normal((ny, nx)), rng.standard_normal((ny, nx))
+    h = 0.25
+    r_ref = np.zeros((ny, nx))
+    oracle.residual(r_ref, a, b, h)
+    da, db, dr = padded(a), padded(b), padded(np.zeros((ny, nx)))
+    slots = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    lib = L.lib()
+    out = C.c_double()
+    for flags in (0, L.FLAG_FINEST):
+        L.check(lib.mg_norm_reset(slots.data_ptr(), st))
+        L.check(lib.mg_residual(dr.data_ptr(), da.data_ptr(), db.data_ptr(), ny, nx, dr.stride(0), 1, ny - 1, h,
+                                slots.data_ptr(), 1, 0, flags, st))
+        L.check(lib.mg_norm_read(slots.data_ptr(), C.byref(out), st))
+        assert out.value == np.abs(r_ref).max()
+        assert np.array_equal(dr.cpu().numpy(), r_ref)
+    # whole-array max, boundary included
+    big = a.copy()
+    big[0, 5] = -1e9
+    L.check(lib.mg_norm_reset(slots.data_ptr(), st))
+    dbig = padded(big)
+    L.check(lib.mg_maxabs(dbig.data_ptr(), ny, nx, dbig.stride(0), slots.data_ptr(), st))
+    L.check(lib.mg_norm_read(slots.data_ptr(), C.byref(out), st))
+    assert out.value == 1e9
+    # a NaN wins, as in np.amax
+    a[100, 200] = np.nan
+    da = padded(a)
+    L.check(lib.mg_norm_reset(slots.data_ptr(), st))
+    L.check(lib.mg_residual(dr.data_ptr(), da.data_ptr(), db.data_ptr(), ny, nx, dr.stride(0), 1, ny - 1, h,
+                            slots.data_ptr(), 1, 0, 0, st))
+    L.check(lib.mg_norm_read(slots.data_ptr(), C.byref(out), st))
+    assert np.isnan(out.value)
+
+
+TRANSFER = [((18, 18), (10, 10)), ((34, 66), (18, 34)), ((130, 130), (66, 66)), ((258, 514), (130, 258)),
+            ((1026, 1026), (514, 514))]
+
+
+@pytest.mark.parametrize("fshape,cshape", TRANSFER, ids=str)
+@pytest.mark.parametrize("oi", [0, -1])
+@pytest.mark.parametrize("oj", [0, -1])
+@pytest.mark.parametrize("pad", [True, False])
+def test_transfer_vs_oracle(mm, fshape, cshape, oi, oj, pad):
+    rng = np.random.default_rng(abs(hash((fshape, oi, oj))) % 10000)
+    f, c0 = rng.standard_normal(fshape), rng.standard_normal(cshape)
+    c_ref = c0.copy()
+    oracle.coarse(f, c_ref, oi, oj)
+    mk = (lambda a: padded(a)) if pad else (lambda a: padded(a, ld=a.shape[1] + 1))
+    dc = mk(c0)
+    mm.coarse(mk(f), dc, oi, oj)
+    assert np.array_equal(dc.cpu().numpy(), c_ref)
+    cc, f0 = rng.standard_normal(cshape), rng.standard_normal(fshape)
+    f_ref = f0.copy()
+    oracle.interpolate_add_to(cc, f_ref, oi, oj)
+    df = mk(f0)
+    mm.interpolate_add_to(mk(cc), df, oi, oj)
+    assert np.array_equal(df.cpu().numpy(), f_ref)
+
+
+@pytest.mark.parametrize("fshape,cshape", [((17, 17), (9, 9)), ((5, 5), (3, 3)), ((513, 1025), (257, 513)),
+                                           ((2049, 2049), (1025, 1025))], ids=str)
+def test_transfer_whole_domain(mm, fshape, cshape):
+    """Offsets 0,0 on grids that include their boundary (the whole-domain levels)."""
+    rng = np.random.default_rng(3)
+    f, c0 = rng.standard_normal(fshape), rng.standard_normal(cshape)
+    c_ref = c0.copy()
+    oracle.coarse(f, c_ref, 0, 0)
+    dc = padded(c0)
+    mm.coarse(padded(f), dc, 0, 0)
+    assert np.array_equal(dc.cpu().numpy(), c_ref)
+    f_ref = f.copy()
+    oracle.interpolate_add_to(c0, f_ref, 0, 0)
+    df = padded(f)
+    mm.interpolate_add_to(padded(c0), df, 0, 0)
+    assert np.array_equal(df.cpu().numpy(), f_ref)
+
+
+SOR_SHAPES = [(3, 3), (4, 7), (9, 9), (33, 33), (65, 257), (129, 129), (141, 139), (1100, 9), (257, 257), (1030, 40)]
+
+
+@pytest.mark.parametrize("shape", SOR_SHAPES, ids=str)
+@pytest.mark.parametrize("its", [1, 3])
+def test_sor_lexicographic_vs_oracle(mm, shape, its):
+    """Wavefront execution (LDS and global-memory variants) == row-major Gauss-Seidel, bit for bit."""
+    rng = np.random.default_rng(shape[0] * 7 + its)
+    b, x0, r0 = rng.standard_normal(shape), rng.standard_normal(shape), rng.standard_normal(shape)
+    for fn in ("smooth", "smooth_altern"):
+        x_ref, r_ref = x0.copy(), r0.copy()
+        getattr(oracle, fn)(b, x_ref, 0.3, r_ref, its)
+        dx, dr = padded(x0), padded(r0)
+        getattr(mm, fn)(padded(b), dx, 0.3, dr, its)
+        assert np.array_equal(dx.cpu().numpy(), x_ref), fn
+        assert np.array_equal(dr.cpu().numpy(), r_ref), fn
+
+
+@pytest.mark.parametrize("shape", [(3, 3), (9, 9), (33, 65), (129, 129), (513, 513)], ids=str)
+def test_sor_redblack_vs_oracle(mm, shape):
+    rng = np.random.default_rng(11)
+    b, x0, r0 = rng.standard_normal(shape), rng.standard_normal(shape), rng.standard_normal(shape)
+    x_ref, r_ref = x0.copy(), r0.copy()
+    oracle.smooth_altern_rb(b, x_ref, 0.3, r_ref, 3)
+    dx, dr = padded(x0), padded(r0)
+    mm.smooth_altern(padded(b), dx, 0.3, dr, 3, ordering="redblack")
+    assert np.array_equal(dx.cpu().numpy(), x_ref)
+    assert np.array_equal(dr.cpu().numpy(), r_ref)
+
+
+def test_batched_kernels(L):
+    """nbatch > 1: every grid of the batch gets the single-grid result."""
+    import torch
+    rng = np.random.default_rng(21)
+    nb, ny, nx = 5, 33, 33
+    ld = 48
+    stride = ny * ld
+    h = 0.5
+
+    def dev(a3):
+        buf = torch.zeros((nb, ny, ld), dtype=torch.float64, device="cuda")
+        buf[:, :, :nx] = torch.from_numpy(a3)
+        return buf
+
+    b, x = rng.standard_normal((nb, ny, nx)), rng.standard_normal((nb, ny, nx))
+    db, dx, do = dev(b), dev(x), dev(x)
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.mg_jacobi(db.data_ptr(), dx.data_ptr(), do.data_ptr(), ny, nx, ld, 1, ny - 1, h, nb, stride, 0, st))
+    got = do.cpu().numpy()[:, :, :nx]
+    for k in range(nb):
+        ref, t = x[k].copy(), x[k].copy()
+        oracle.smooth_sweep_jacobi(b[k], ref, t, h)
+        assert np.array_equal(got[k], ref)
+    dr = dev(np.zeros((nb, ny, nx)))
+    L.check(lib.mg_sor(db.data_ptr(), dx.data_ptr(), dr.data_ptr(), ny, nx, ld, h, 3, 1, L.SOR_LEXICOGRAPHIC, nb, stride,
+                       st))
+    gx, gr = dx.cpu().numpy()[:, :, :nx], dr.cpu().numpy()[:, :, :nx]
+    for k in range(nb):
+        xr, rr = x[k].copy(), np.zeros((ny, nx))
+        oracle.smooth_altern(b[k], xr, h, rr, 3)
+        assert np.array_equal(gx[k], xr)
+        assert np.array_equal(gr[k], rr)
+    # restriction / prolongation, batched
+    cny = cnx = 17
+    cld = 32
+    c = dev(np.zeros((nb, ny, nx)))[:, :cny, :cld].contiguous()
+    L.check(lib.mg_restrict(dx.data_ptr(), ny, nx, ld, c.data_ptr(), cny, cnx, cld, 1, cny - 1, 0, 0, nb, stride,
+                            cny * cld, st))
+    gc = c.cpu().numpy()[:, :, :cnx]
+    for k in range(nb):
+        cr = np.zeros((cny, cnx))
+        oracle.coarse(gx[k].copy(), cr, 0, 0)
+        assert np.array_equal(gc[k], cr)
+    L.check(lib.mg_prolong_add(c.data_ptr(), cny, cnx, cld, dx.data_ptr(), ny, nx, ld, 0, ny, 0, nx - 1, 0, 0, nb,
+                               cny * cld, stride, st))
+    gx2 = dx.cpu().numpy()[:, :, :nx]
+    for k in range(nb):
+        fr = gx[k].copy()
+        oracle.interpolate_add_to(np.ascontiguousarray(gc[k]), fr, 0, 0)
+        assert np.array_equal(gx2[k], fr)
+
+
+def test_error_behaviour(mm, L):
+    """Wrong dtype/rank -> TypeError (as the compiled reference module); bad shapes are rejected
+    on the host before any launch."""
+    import torch
+    a = np.zeros((10, 10))
+    with pytest.raises(TypeError):
+        mm.residual(a.astype(np.float32), a, a, 1.0)
+    with pytest.raises(TypeError):
+        mm.residual(a[0], a, a, 1.0)
+    with pytest.raises(TypeError):
+        mm.coarse(torch.zeros(10, 10, dtype=torch.float64), a, 0, 0)  # CPU tensor
+    with pytest.raises(L.MgError):
+        mm.residual(a, a, np.zeros((10, 11)), 1.0)
+    with pytest.raises(L.MgError):
+        mm.coarse(np.zeros((10, 10)), np.zeros((10, 10)), 0, 0)  # fine grid too small
+    with pytest.raises(L.MgError):
+        mm.interpolate_add_to(np.zeros((10, 10)), np.zeros((10, 10)), 0, 0)
+    with pytest.raises(L.MgError):
+        mm.coarse(np.zeros((18, 18)), np.zeros((10, 10)), 1, 0)
+    lib = L.lib()
+    d = padded(a)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.mg_jacobi(d.data_ptr(), d.data_ptr(), d.data_ptr(), 10, 10, 16, 1, 9, 1.0, 1, 0, 0, st) != 0
+    assert b"alias" in lib.mg_last_error()
+    assert lib.mg_jacobi(d.data_ptr(), d.data_ptr(), None, 10, 10, 16, 0, 9, 1.0, 1, 0, 0, st) != 0
+    # rank outside 0..3: the reference copies nothing
+    o = np.full((5, 5), 3.0)
+    mm.split(a, o, 7)
+    assert np.all(o == 3.0)
