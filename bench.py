@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the multigrid V-cycle hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one V-cycle of the reference schedule (3 pre / 6 post Jacobi sweeps per Jacobi level,
+3 symmetric SOR sweeps on the first whole-domain level, residual + max-norm on the finest level,
+convergence value read back by the host) on a right-hand side that is already resident in HBM.
+
+Workload: the configuration BASELINE.json's metric is quoted on -- a 32769 x 32769 float64 grid
+(n = 14, ~1.07e9 unknowns, 46 GB of level arrays) per GPU.  With N > 1 ranks (one process per GPU,
+launched by torch.distributed.run) every rank keeps that slab and the global grid grows to
+(N * 32768 + 1) x 32769 rows x columns: weak scaling.  The halo rows travel by RCCL send/recv, the
+whole-domain levels are gathered onto rank 0.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel (finest-level Jacobi sweep): algorithmic bytes per launch
+                (24 B per updated point) / its average duration, timed here with HIP events on the
+                stream the kernel runs on, against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (C restatement of the reference algorithm, OpenMP over rows) timed
+                on this host's cores on a bounded sample (a smaller grid, a few V-cycles)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=14, help="grid is (2**(n+1)+1) columns wide; 14 -> 32769")
+    ap.add_argument("--n-para", type=int, default=8, help="number of Jacobi (slab-distributed) levels")
+    ap.add_argument("--ordering", default="lexicographic", choices=["lexicographic", "redblack"])
+    ap.add_argument("--roofline-iters", type=int, default=20)
+    ap.add_argument("--cpu-n", type=int, default=12, help="grid exponent of the CPU baseline sample")
+    ap.add_argument("--cpu-cycles", type=int, default=0, help="0 = choose for roughly 15 s")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def fill_rhs(eng, torch, n, rank):
+    """The eight-vortex right-hand side of the reference's test driver (test/test.py:40-58), built on
+    the device slab by slab.  Rows beyond the first 20-unit band repeat the pattern so that every
+    rank's slab carries the same kind of data."""
+    P = eng.plan
+    gnx = P.gnx
+    h = 20.0 / 2 ** (n + 1)
+    dev = eng.b0.device
+    X = torch.linspace(-10, 10, gnx, dtype=torch.float64, device=dev)
+    xr = [4, -2, 6, 3, 3, 5, -5, -7]
+    yr = [-2, 6, 6, -5, 5, -5, -2, -2]
+    a, e = eng.owned_rows()
+    band = 2 ** (n + 1)
+    chunk = 256
+    for t in range(a, e, chunk):
+        t2 = min(t + chunk, e)
+        g = torch.arange(t, t2, device=dev, dtype=torch.float64) + (rank * P.levels[0].rows - 1)
+        Y = (-10.0 + h * torch.remainder(g, band)).unsqueeze(1)
+        acc = torch.zeros((t2 - t, gnx), dtype=torch.float64, device=dev)
+        sign = 1.0
+        for xv, yv in zip(xr, yr):
+            acc += sign * 50.0 * torch.exp(-7.0 * ((X.unsqueeze(0) - xv) ** 2 + (Y - yv) ** 2))
+            sign = -sign
+        eng.b0[t:t2, :gnx] = acc
+    # Dirichlet boundary cells carry no equation
+    eng.b0[:, 0] = 0
+    eng.b0[:, gnx - 1] = 0
+    if rank == 0:
+        eng.b0[1, :] = 0
+    if rank == eng.world - 1:
+        eng.b0[P.levels[0].rows + 1, :] = 0
+    return h
+
+
+def cpu_baseline(args):
+    import numpy as np
+    import oracle
+    from tests.rhs import test_rhs
+    n = args.cpu_n
+    N = 2 ** (n + 1) + 1
+    # keep n - n_para (hence the size of the whole-domain level) as in the GPU workload
+    n_para = max(1, min(n - 1, args.n_para - (args.n - n)))
+    b0, h = test_rhs(n)
+    s = oracle.GlobalSolver(N, N, n_para, h, 0.0, "lexicographic")
+    s.b[:] = b0
+    t0 = time.perf_counter()
+    s.solve(ncycles=1)
+    t1 = time.perf_counter() - t0
+    cycles = args.cpu_cycles or max(2, min(60, int(15.0 / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    s.solve(ncycles=cycles)
+    dt = time.perf_counter() - t0
+    unknowns = (N - 2) * (N - 2)
+    return {
+        "value": unknowns * cycles / dt, "unit": "unknowns*V-cycles/s", "cores": oracle.num_threads(),
+        "kind": "port",
+        "sample": f"{cycles} V-cycles on a {N}x{N} grid (n={n}, n_para={n_para}), C restatement of the reference "
+                  f"algorithm with OpenMP row-parallel sweeps, {dt:.1f} s",
+        "ms_per_cycle": 1e3 * dt / cycles,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from multigrid_amd.engine import SlabMultigrid
+    from multigrid_amd.levels import algorithmic_bytes_per_cycle
+
+    n, n_para = args.n, args.n_para
+    gnx = 2 ** (n + 1) + 1
+    gny = world * 2 ** (n + 1) + 1
+    h = 20.0 / 2 ** (n + 1)
+    eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
+                        use_graph=not args.no_graph)
+    fill_rhs(eng, torch, n, rank)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.presmooth()
+    errs = eng.cycles(args.warmup) if args.warmup else []
+    barrier()
+    t0 = time.perf_counter()
+    errs += eng.cycles(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- dominant kernel: finest-level Jacobi sweep, HIP events on the engine's stream
+    L0 = eng.plan.levels[0]
+    ops = eng.ops
+    xs = [eng._xa[0], eng._xb[0]]
+    iters = args.roofline_iters
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.begin()
+    for _ in range(2):
+        ops.jacobi(eng.b[0], xs[0], xs[1], L0.nx, L0.t0, L0.t1, L0.h, True)
+    ev0.record(ops.stream)
+    for k in range(iters):
+        ops.jacobi(eng.b[0], xs[k & 1], xs[1 - (k & 1)], L0.nx, L0.t0, L0.t1, L0.h, True)
+    ev1.record(ops.stream)
+    ops.stream.synchronize()
+    sweep_ms = ev0.elapsed_time(ev1) / iters
+    pts_launch = (L0.t1 - L0.t0) * (L0.nx - 2)
+    alg_bytes_launch = 24 * pts_launch
+    achieved = alg_bytes_launch / (sweep_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        unknowns = (gny - 2) * (gnx - 2)
+        ms = 1e3 * dt / args.steps
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("jacobi_finest_bytes_per_launch")
+            except Exception:
+                traffic = None
+        bcyc = algorithmic_bytes_per_cycle(eng.plan)
+        out = {
+            "metric": "unknowns*V-cycles/s", "value": unknowns * args.steps / dt, "unit": "unknowns*V-cycles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{gny}x{gnx} fp64 Poisson V-cycle ({gnx}x{gnx} per GPU), test.py 8-vortex RHS",
+                "n": n, "n_para": n_para, "grid": [gny, gnx], "unknowns": unknowns,
+                "coarse_ordering": args.ordering, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
+                "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph),
+            },
+            "roofline": {
+                "kernel": "mg_stencil5_kernel<OP_JACOBI, V=4, FINEST> (finest-level Jacobi sweep)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": sweep_ms, "launches_timed": iters,
+            },
+            "cycle": {
+                "algorithmic_bytes": bcyc, "gbps_per_gpu": bcyc / world / (ms * 1e-3) / 1e9,
+                "frac_of_peak": bcyc / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "max_abs_r_after_last_cycle": errs[-1] if errs else None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # the GPU numbers stand on their own
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

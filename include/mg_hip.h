@@ -138,6 +138,9 @@ int mg_sor(const double *b, double *x, double *r, int64_t ny, int64_t nx, int64_
  */
 int mg_copy2d(double *dst, int64_t dld, const double *src, int64_t sld, int64_t ny, int64_t nx, void *stream);
 
+/* a[0:n] = 0.0 (the `x[:] = 0` of core/parallel_multigrid.py:276,291,295), as a memset node. */
+int mg_zero(double *a, int64_t n, void *stream);
+
 /* split(A_in, A_out, rank), core/numba_modules.py:10-20: A_out (nout x nout) = corner `rank` of A_in. */
 int mg_split(const double *a_in, int64_t in_ny, int64_t in_nx, int64_t in_ld, double *a_out, int64_t nout,
              int64_t out_ld, int64_t rank, void *stream);

@@ -223,6 +223,13 @@ extern "C" int mg_copy2d(double *dst, i64 dld, const double *src, i64 sld, i64 n
     return 0;
 }
 
+extern "C" int mg_zero(double *a, i64 n, void *stream)
+{
+    MG_REQUIRE(a && n >= 0, "mg_zero: bad argument");
+    if (n) MG_HIP(hipMemsetAsync(a, 0, (size_t)n * sizeof(double), (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int mg_split(const double *a_in, i64 in_ny, i64 in_nx, i64 in_ld, double *a_out, i64 nout, i64 out_ld,
                         i64 rank, void *stream)
 {

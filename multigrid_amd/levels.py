@@ -1,0 +1,137 @@
+"""Level shapes and row-slab partition arithmetic (host only, no GPU needed).
+
+Two layouts appear in this package:
+
+* the reference's: four square sub-domain blocks of side 2**(n-i)+2 per level i < n_para plus
+  whole-domain levels of side 2**(n-i)+1 for i = n_para-1 .. n-1
+  (Multigrid.__init__, core/parallel_multigrid.py:182-219 of the reference checkout);
+* this package's: the global (NY x NX) grid, boundary included, cut into P row slabs for the
+  n_para Jacobi levels; every coarser grid lives whole on rank 0.
+
+`reference_layout` restates the first (used by the drop-in `Multigrid` and by tests),
+`SlabPlan` describes the second.
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+
+def reference_layout(n, n_para, h0=1.0):
+    """Shapes and mesh widths of every level the reference allocates for (n, n_para)."""
+    if not n_para < n:
+        raise AssertionError("n_para < n")  # parallel_multigrid.py:159
+    wl = [2 ** (n - i) + 1 for i in range(n_para - 1, n)]
+    h_wl = [h0 * 2 ** (i + 1) for i in range(n_para - 1, n)]
+    sb = [2 ** (n - i) + 2 for i in range(n_para)]
+    h_sb = [h0 * 2 ** i for i in range(n_para)]
+    b_sb = sb + [2 ** (n - n_para) + 2]
+    return {
+        "x_sb": [[m, m] for m in sb], "r_sb": [[m, m] for m in sb], "b_sb": [[m, m] for m in b_sb],
+        "x_wl": [[m, m] for m in wl], "b_wl": [[m, m] for m in wl], "h_sb": h_sb, "h_wl": h_wl,
+    }
+
+
+# offsets of the four block ranks (parallel_multigrid.py:222-228) and their neighbours (:49-56)
+BLOCK_OFFSETS = [{"j": 0, "i": 0}, {"j": 0, "i": -1}, {"j": -1, "i": 0}, {"j": -1, "i": -1}]
+BLOCK_NEIGHBOURS = [{"east": 1, "north": 2}, {"west": 0, "north": 3}, {"east": 3, "south": 0},
+                    {"west": 2, "south": 1}]
+
+
+def pitch(nx, align=16):
+    """Leading dimension for nx columns: a multiple of 16 doubles (128 B) so that every row starts
+    on a cache-line boundary and the widest vector loads are aligned."""
+    return (nx + align - 1) // align * align
+
+
+@dataclass
+class SlabLevel:
+    """One Jacobi level on one rank.  Local row t holds global row rank*rows - 1 + t: row 0 is the
+    halo above (unused on rank 0), rows 1..rows are owned, row rows+1 is the halo below (on the last
+    rank: the global boundary row)."""
+    level: int
+    rows: int          # owned rows R_l (the last rank additionally holds the boundary row as t = R_l+1)
+    ny: int            # local rows = rows + 2
+    nx: int            # global columns, boundary included
+    ld: int
+    h: float
+    t0: int            # first local row that is updated (global row 0 is boundary)
+    t1: int            # one past the last updated local row
+    gny: int           # global rows at this level
+
+
+@dataclass
+class WholeLevel:
+    """A grid that lives whole on rank 0 (the reference's x_wl/b_wl/r_wl levels)."""
+    ny: int
+    nx: int
+    ld: int
+    h: float
+
+
+@dataclass
+class SlabPlan:
+    gny: int
+    gnx: int
+    n_para: int
+    world: int
+    rank: int
+    h0: float
+    levels: List[SlabLevel] = field(default_factory=list)  # 0 .. n_para (the last one is the staging level)
+    whole: List[WholeLevel] = field(default_factory=list)
+
+    @property
+    def unknowns(self):
+        return (self.gny - 2) * (self.gnx - 2)
+
+
+def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0):
+    """Partition a (gny x gnx) grid (boundary included) for `n_para` Jacobi levels over `world` ranks.
+
+    Requirements: gny-1 = world * R with R divisible by 2**n_para (so that coarse row g/2 lives on
+    the rank that owns fine row g on every Jacobi level, and slab boundaries fall on even rows),
+    gnx-1 divisible by 2**n_para, and at least 2 cells per side on the first whole-domain level.
+    """
+    if n_para < 1:
+        raise ValueError("n_para >= 1 required")
+    if (gny - 1) % world:
+        raise ValueError(f"{gny - 1} rows of cells cannot be split evenly over {world} ranks")
+    R0 = (gny - 1) // world
+    if R0 % (1 << n_para) or (gnx - 1) % (1 << n_para):
+        raise ValueError(f"rows per rank ({R0}) and columns-1 ({gnx - 1}) must be divisible by 2**n_para = {1 << n_para}")
+    if ((gny - 1) >> n_para) < 2 or ((gnx - 1) >> n_para) < 2:
+        raise ValueError("the first whole-domain level needs at least 2 cells per side")
+    plan = SlabPlan(gny, gnx, n_para, world, rank, h0)
+    for l in range(n_para + 1):
+        R = R0 >> l
+        nx = ((gnx - 1) >> l) + 1
+        plan.levels.append(SlabLevel(level=l, rows=R, ny=R + 2, nx=nx, ld=pitch(nx), h=h0 * 2 ** l,
+                                     t0=2 if rank == 0 else 1, t1=R + 1, gny=((gny - 1) >> l) + 1))
+    l = n_para
+    while True:
+        my, mx = (gny - 1) >> l, (gnx - 1) >> l
+        if my < 2 or mx < 2 or (my << l) != gny - 1 or (mx << l) != gnx - 1:
+            break
+        plan.whole.append(WholeLevel(ny=my + 1, nx=mx + 1, ld=pitch(mx + 1), h=h0 * 2 ** l))
+        l += 1
+    return plan
+
+
+def exchanges_per_cycle(n_para):
+    """Halo exchanges one V-cycle performs per rank (see engine.SlabMultigrid._cycle)."""
+    return 8 + 11 * (n_para - 1)
+
+
+def algorithmic_bytes_per_cycle(plan, keep_ascent_residuals=False, fused_zero_sweep=True):
+    """Compulsory HBM traffic of one V-cycle over the whole grid, in bytes (float64):
+    Jacobi sweep 24 B/pt, residual 24, restriction 10 per fine point, prolongation 18 per fine
+    point; the zero-fill of a coarse x is 0 when fused into the first sweep (which then moves 16
+    B/pt instead of 24), else 8.  Whole-domain levels are included as their smoother traffic."""
+    total = 0
+    for l in range(plan.n_para):
+        pts = (((plan.gny - 1) >> l) + 1) * (((plan.gnx - 1) >> l) + 1)
+        if l == 0:
+            per = 10 + 18 + 6 * 24 + 24
+        else:
+            first = 16 if fused_zero_sweep else 8 + 24
+            per = first + 2 * 24 + 24 + 10 + 18 + 6 * 24 + (24 if keep_ascent_residuals else 0)
+        total += per * pts
+    return total

@@ -1,0 +1,118 @@
+"""The kernel set the V-cycle engine is written against, bound to libmg_hip.so.
+
+`HipOps` is a thin object: each method takes full-pitch 2-D float64 CUDA tensors (rows x ld) plus
+the logical column count, and enqueues one call of the C ABI (include/mg_hip.h) on `stream`.
+The engine only ever talks to an object with this interface.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.MgError("no GPU visible: multigrid_amd runs on MI355X only and has no CPU path")
+        self.L = _lib.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        # a stream of its own: the null stream cannot be captured into a hipGraph
+        self.stream = torch.cuda.Stream(self.device)
+
+    # ---- memory / stream plumbing (torch) -------------------------------------------------
+    def zeros(self, rows, ld):
+        return torch.zeros((rows, ld), dtype=torch.float64, device=self.device)
+
+    def norm_slots(self):
+        return torch.zeros(_lib.NORM_SLOTS, dtype=torch.int64, device=self.device)
+
+    @property
+    def _s(self):
+        return self.stream.cuda_stream
+
+    def ctx(self):
+        """Context in which torch ops and torch.distributed calls are ordered with the kernels."""
+        return torch.cuda.stream(self.stream)
+
+    def begin(self):
+        """Order this object's stream after whatever the caller enqueued on torch's current stream."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def end(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def zero_(self, t):
+        """t[:] = 0 for a tensor that covers whole rows of its allocation (contiguous memory)."""
+        assert t.is_contiguous()
+        check(self.L.mg_zero(t.data_ptr(), t.numel(), self._s))
+
+    def copy_(self, dst, src):
+        assert dst.shape == src.shape and dst.stride(0) == src.stride(0)
+        check(self.L.mg_copy2d(dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), dst.shape[0],
+                               dst.shape[1], self._s))
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    # ---- kernels ---------------------------------------------------------------------------
+    def jacobi(self, b, x, xo, nx, j0, j1, h, finest=False):
+        check(self.L.mg_jacobi(b.data_ptr(), x.data_ptr(), xo.data_ptr(), x.shape[0], nx, x.stride(0), j0, j1, h, 1, 0,
+                               _lib.FLAG_FINEST if finest else 0, self._s))
+
+    def jacobi_from_zero(self, b, xo, nx, j0, j1, h, finest=False):
+        check(self.L.mg_jacobi_from_zero(b.data_ptr(), xo.data_ptr(), xo.shape[0], nx, xo.stride(0), j0, j1, h, 1, 0,
+                                         _lib.FLAG_FINEST if finest else 0, self._s))
+
+    def residual(self, r, x, b, nx, j0, j1, h, norm=None, finest=False):
+        check(self.L.mg_residual(r.data_ptr(), x.data_ptr(), b.data_ptr(), x.shape[0], nx, x.stride(0), j0, j1, h,
+                                 norm.data_ptr() if norm is not None else None, 1, 0,
+                                 _lib.FLAG_FINEST if finest else 0, self._s))
+
+    def restrict(self, f, fnx, c, cnx, J0, J1, oi, oj):
+        check(self.L.mg_restrict(f.data_ptr(), f.shape[0], fnx, f.stride(0), c.data_ptr(), c.shape[0], cnx,
+                                 c.stride(0), J0, J1, oi, oj, 1, 0, 0, self._s))
+
+    def prolong_add(self, c, cnx, f, fnx, t0, t1, oi, oj):
+        check(self.L.mg_prolong_add(c.data_ptr(), c.shape[0], cnx, c.stride(0), f.data_ptr(), f.shape[0], fnx,
+                                    f.stride(0), t0, t1, 1, fnx - 2, oi, oj, 1, 0, 0, self._s))
+
+    def sor(self, b, x, r, nx, h, iterations, ordering):
+        check(self.L.mg_sor(b.data_ptr(), x.data_ptr(), r.data_ptr() if r is not None else None, x.shape[0], nx,
+                            x.stride(0), h, iterations, 1,
+                            {"lexicographic": _lib.SOR_LEXICOGRAPHIC, "redblack": _lib.SOR_REDBLACK}[ordering], 1, 0,
+                            self._s))
+
+    def norm_reset(self, slots):
+        check(self.L.mg_norm_reset(slots.data_ptr(), self._s))
+
+    def norm_read(self, slots):
+        """max of the accumulator; waits for the stream."""
+        out = C.c_double()
+        check(self.L.mg_norm_read(slots.data_ptr(), C.byref(out), self._s))
+        return out.value
+
+    def norm_tensor(self, slots):
+        """the accumulator's max as a 1-element device tensor (no host sync), for a collective"""
+        with torch.cuda.stream(self.stream):
+            return slots.view(torch.float64).max().reshape(1)
+
+    # ---- hipGraph ----------------------------------------------------------------------------
+    supports_graphs = True
+
+    def graph_begin(self):
+        check(self.L.mg_graph_begin(self._s))
+
+    def graph_end(self):
+        g = C.c_void_p()
+        check(self.L.mg_graph_end(self._s, C.byref(g)))
+        return g
+
+    def graph_launch(self, g):
+        check(self.L.mg_graph_launch(g, self._s))
+
+    def graph_destroy(self, g):
+        check(self.L.mg_graph_destroy(g))

@@ -67,6 +67,7 @@ def lib():
         L.orc_global_array.restype = C.POINTER(C.c_double)
         L.orc_global_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_global_solve.restype = C.c_int
+        L.orc_num_threads.restype = C.c_int
         _lib = L
     return _lib
 
@@ -109,6 +110,10 @@ def coarse(a, a_crs, ofst_i, ofst_j):
 
 def interpolate_add_to(a, a_new, ofst_i, ofst_j):
     lib().orc_interpolate_add_to(a, a.shape[0], a.shape[1], a_new, a_new.shape[0], a_new.shape[1], ofst_i, ofst_j)
+
+
+def num_threads():
+    return lib().orc_num_threads()
 
 
 def maxabs(a):

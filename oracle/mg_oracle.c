@@ -29,7 +29,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 typedef int64_t i64;
+
+/* number of host threads the row-parallel loops below use */
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------ kernels */
 

@@ -1,0 +1,173 @@
+"""Host logic of the slab engine, checked without a GPU: the engine runs with the oracle-backed
+ops (tests/oracle_ops.py) single-process and under torch.distributed/gloo with 2 and 4 ranks, and
+must reproduce oracle.GlobalSolver (the reference schedule on the undecomposed grid) bit for bit:
+Jacobi, residual and the transfer operators are order-free, so how the rows are cut cannot matter.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from multigrid_amd.engine import SlabMultigrid
+from multigrid_amd.levels import exchanges_per_cycle, make_plan, reference_layout
+from tests.oracle_ops import OracleOps
+from tests.rhs import test_rhs as vortex_rhs
+
+
+def _rhs(gny, gnx, seed=0):
+    rng = np.random.default_rng(seed)
+    b = rng.standard_normal((gny, gnx))
+    b[0] = b[-1] = 0
+    b[:, 0] = b[:, -1] = 0
+    return b
+
+
+def _engine_run(gny, gnx, n_para, h, b, world, rank, cycles, group=None, **kw):
+    eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, ops=OracleOps(), world=world, rank=rank, group=group, **kw)
+    R = eng.plan.levels[0].rows
+    a, e = eng.owned_rows()
+    g0 = rank * R
+    eng.set_b_rows(torch.from_numpy(b[g0 : g0 + (e - a)]))
+    eng.presmooth()
+    errs = eng.cycles(cycles)
+    return eng, errs, eng.local_rows(eng.x0).numpy().copy(), eng.local_rows(eng.r0).numpy().copy()
+
+
+CASES = [(65, 65, 2), (129, 129, 3), (65, 129, 3), (257, 33, 2), (33, 33, 1)]
+
+
+@pytest.mark.parametrize("gny,gnx,n_para", CASES, ids=str)
+@pytest.mark.parametrize("ordering", ["lexicographic", "redblack"])
+def test_single_rank_equals_global_oracle(gny, gnx, n_para, ordering):
+    b = _rhs(gny, gnx)
+    h = 0.37
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0, ordering)
+    ref.b[:] = b
+    ref.solve(ncycles=4)
+    eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, 1, 0, 4, coarse_ordering=ordering)
+    assert errs == ref.err_hist.tolist()
+    assert np.array_equal(x, ref.x)
+    assert np.array_equal(r, ref.r)
+    # whole-domain levels, dead ones included, match the oracle's
+    for k in range(len(eng.plan.whole)):
+        W = eng.plan.whole[k]
+        assert np.array_equal(eng.xw[k].numpy()[:, : W.nx], ref.array("xw", k))
+        assert np.array_equal(eng.rw[k].numpy()[:, : W.nx], ref.array("rw", k))
+
+
+def test_fix_coarse_ascent_and_ascent_residuals():
+    gny = gnx = 129
+    b = _rhs(gny, gnx, 3)
+    ref = oracle.GlobalSolver(gny, gnx, 2, 0.5, 0.0, "lexicographic", fix_coarse_ascent=True)
+    ref.b[:] = b
+    ref.solve(ncycles=3)
+    eng, errs, x, _ = _engine_run(gny, gnx, 2, 0.5, b, 1, 0, 3, fix_coarse_ascent=True, keep_ascent_residuals=True)
+    assert errs == ref.err_hist.tolist()
+    assert np.array_equal(x, ref.x)
+    L1 = eng.plan.levels[1]
+    assert np.array_equal(eng.r[1].numpy()[1 : L1.rows + 2, : L1.nx], ref.array("r", 1))
+    # the textbook ascent converges faster than the reference's loop bounds allow
+    ref2 = oracle.GlobalSolver(gny, gnx, 2, 0.5, 0.0, "lexicographic")
+    ref2.b[:] = b
+    ref2.solve(ncycles=3)
+    assert ref.err_hist[-1] < ref2.err_hist[-1]
+
+
+def test_solve_stop_rule_matches_oracle():
+    n, n_para = 5, 2
+    b0, h = vortex_rhs(n)
+    N = 2 ** (n + 1) + 1
+    ref = oracle.GlobalSolver(N, N, n_para, h, 0.025)
+    ref.b[:] = b0
+    e_ref = ref.solve()
+    eng = SlabMultigrid(N, N, n_para, h, 0.025, ops=OracleOps(), world=1, rank=0)
+    eng.set_b_rows(torch.from_numpy(b0))
+    e = eng.solve()
+    assert (e, eng.it) == (e_ref, ref.it)
+    assert eng.err_history == ref.err_hist.tolist()
+    # warm start: a second solve continues from the current x
+    e2 = eng.solve()
+    e2_ref = ref.solve()
+    assert (e2, eng.it) == (e2_ref, ref.it)
+
+
+def test_plan_and_layout():
+    import json
+    lay = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "layout.json")))
+    for L in lay["levels"]:
+        mine = reference_layout(L["n"], L["n_para"], 1.0)
+        for k in ("x_sb", "b_sb", "r_sb", "x_wl", "b_wl", "h_sb", "h_wl"):
+            assert mine[k] == L[k], (L["n"], L["n_para"], k)
+    with pytest.raises(AssertionError):
+        reference_layout(4, 4)
+    p = make_plan(32769, 32769, 8, world=8, rank=3, h0=1.0)
+    assert [L.rows for L in p.levels] == [4096 >> l for l in range(9)]
+    assert p.levels[0].ld % 16 == 0 and p.levels[0].ld >= 32769
+    assert (p.whole[0].ny, p.whole[0].nx) == (129, 129) and len(p.whole) == 7 and p.whole[-1].ny == 3
+    assert p.levels[0].t0 == 1 and make_plan(32769, 32769, 8, 8, 0).levels[0].t0 == 2
+    with pytest.raises(ValueError):
+        make_plan(65, 65, 2, world=3)
+    with pytest.raises(ValueError):
+        make_plan(65, 65, 6)
+    with pytest.raises(ValueError):
+        make_plan(67, 65, 2)
+    assert exchanges_per_cycle(4) == 8 + 33
+
+
+# ------------------------------------------------------------------ multi-rank, gloo
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, world, rank, cycles)
+        q.put((rank, errs, x, r))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,gny,gnx,n_para", [(2, 65, 65, 2), (2, 129, 65, 3), (4, 129, 129, 3), (4, 257, 33, 2)],
+                         ids=str)
+def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para):
+    b = _rhs(gny, gnx, 7)
+    h = 0.37
+    cycles = 3
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0)
+    ref.b[:] = b
+    ref.solve(ncycles=cycles)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        rank, errs, x, r = q.get(timeout=240)
+        out[rank] = (errs, x, r)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = np.concatenate([out[k][1] for k in range(world)], axis=0)
+    r = np.concatenate([out[k][2] for k in range(world)], axis=0)
+    for k in range(world):
+        assert out[k][0] == ref.err_hist.tolist()  # every rank sees the global max-norm
+    assert np.array_equal(x, ref.x)
+    assert np.array_equal(r, ref.r)

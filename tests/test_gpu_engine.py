@@ -1,0 +1,161 @@
+"""The slab engine on the MI355X (HIP kernels through the C ABI) against the CPU oracle and the
+golden vectors of the reference.  Marked gpu.
+
+Tolerances:
+* engine vs oracle.GlobalSolver (same schedule on the undecomposed grid): bit-exact, both for the
+  lexicographic coarse smoother (the reference's ordering) and for the red-black one;
+* engine vs the reference's own 4-rank runs (tests/golden/solve_*.npz): the per-cycle max|r| agrees
+  to 1e-4 relative on the reference's test right-hand side -- the remaining difference is the
+  reference's one-exchange-old corner halo cell that enters its restriction at the point where the
+  four blocks meet (the block oracle reproduces it, the global layout has no such cell);
+* converged solution vs a direct solve of the 5-point system: 1e-10 relative L2.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.rhs import main_rhs
+from tests.rhs import test_rhs as vortex_rhs
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _make(gny, gnx, n_para, h, eps, b, **kw):
+    import torch
+    from multigrid_amd.engine import SlabMultigrid
+    eng = SlabMultigrid(gny, gnx, n_para, h, eps, world=1, rank=0, **kw)
+    eng.set_b_rows(torch.from_numpy(np.ascontiguousarray(b)).cuda())
+    return eng
+
+
+def _rows(eng, arr):
+    return eng.local_rows(arr).cpu().numpy()
+
+
+def _rhs(gny, gnx, seed=0):
+    rng = np.random.default_rng(seed)
+    b = rng.standard_normal((gny, gnx))
+    b[0] = b[-1] = 0
+    b[:, 0] = b[:, -1] = 0
+    return b
+
+
+CASES = [(65, 65, 2), (129, 129, 3), (65, 129, 3), (257, 33, 2), (33, 33, 1), (1025, 1025, 4), (513, 2049, 5)]
+
+
+@pytest.mark.parametrize("gny,gnx,n_para", CASES, ids=str)
+@pytest.mark.parametrize("ordering", ["lexicographic", "redblack"])
+@pytest.mark.parametrize("graph", [True, False])
+def test_engine_equals_global_oracle(gny, gnx, n_para, ordering, graph):
+    b = _rhs(gny, gnx)
+    h = 0.37
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0, ordering)
+    ref.b[:] = b
+    ref.solve(ncycles=4)
+    eng = _make(gny, gnx, n_para, h, 0.0, b, coarse_ordering=ordering, use_graph=graph)
+    eng.presmooth()
+    errs = eng.cycles(4)
+    assert errs == ref.err_hist.tolist()
+    assert np.array_equal(_rows(eng, eng.x0), ref.x)
+    assert np.array_equal(_rows(eng, eng.r0), ref.r)
+    for k, W in enumerate(eng.plan.whole):
+        assert np.array_equal(eng.xw[k].cpu().numpy()[:, : W.nx], ref.array("xw", k))
+    eng.close()
+
+
+def test_fix_coarse_ascent_equals_oracle():
+    gny = gnx = 257
+    b = _rhs(gny, gnx, 3)
+    ref = oracle.GlobalSolver(gny, gnx, 3, 0.5, 0.0, "lexicographic", fix_coarse_ascent=True)
+    ref.b[:] = b
+    ref.solve(ncycles=3)
+    eng = _make(gny, gnx, 3, 0.5, 0.0, b, fix_coarse_ascent=True, keep_ascent_residuals=True)
+    eng.presmooth()
+    assert eng.cycles(3) == ref.err_hist.tolist()
+    assert np.array_equal(_rows(eng, eng.x0), ref.x)
+
+
+def _global_rhs_from_blocks(g, nsolve_index):
+    """The global right-hand side of solve number `nsolve_index` of a golden run: test.py mutates the
+    four blocks in place before every solve (test/test.py:77-78); stitch them as gather_blocks does."""
+    n = int(g["n"])
+    b0, h = (vortex_rhs if str(g["rhs"]) == "test" else main_rhs)(n)
+    blocks = [np.zeros((2 ** n + 2, 2 ** n + 2)) for _ in range(4)]
+    for k in range(4):
+        oracle.split(b0, blocks[k], k)
+    out = []
+    for _ in range(nsolve_index + 1):
+        if int(g["mutate"]):
+            for k in range(4):
+                blocks[k][1:-1] += blocks[k][0:-2]
+                blocks[k][:] /= 2
+        full = np.zeros_like(b0)
+        oracle.gather_blocks(blocks, full)
+        out.append(full)
+    return out, h
+
+
+@pytest.mark.parametrize("name", ["t_n5_p4", "t_n6_p3", "t_n6_p5", "t_n7_p4", "t_n8_p4"])
+def test_history_matches_reference_runs(name):
+    """Same right-hand sides as the reference's 4-rank runs (warm-started solves included): same
+    V-cycle counts and per-cycle max|r| within 1e-4 relative of the reference's history."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, f"solve_{name}.npz"))
+    n, n_para = int(g["n"]), int(g["n_para"])
+    N = 2 ** (n + 1) + 1
+    rhs, h = _global_rhs_from_blocks(g, int(g["nsolves"]) - 1)
+    eng = _make(N, N, n_para, h, float(g["eps"]), rhs[0])
+    ref_hist = g["err_cycle"].max(axis=0)
+    pos = 0
+    for s in range(int(g["nsolves"])):
+        eng.set_b_rows(torch.from_numpy(rhs[s]).cuda())
+        err = eng.solve()
+        it_ref = int(g["its"][0][s])
+        assert eng.it == it_ref
+        ref = ref_hist[pos : pos + it_ref]
+        pos += it_ref
+        rel = np.abs(np.array(eng.err_history) - ref) / ref
+        assert rel.max() < 1e-4, (s, rel.max())
+        assert abs(err - g["errs"][:, s].max()) / err < 1e-4
+
+
+def test_converged_solution_matches_direct_solve():
+    """Run V-cycles to stagnation and compare with a sparse direct solve of the same 5-point system."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    n, n_para = 5, 2
+    b0, h = main_rhs(n)
+    N = 2 ** (n + 1) + 1
+    m = N - 2
+    T = sp.diags([np.ones(m - 1), -2 * np.ones(m), np.ones(m - 1)], [-1, 0, 1])
+    A = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))) / h ** 2
+    x_direct = np.zeros((N, N))
+    x_direct[1:-1, 1:-1] = spla.spsolve(A.tocsc(), b0[1:-1, 1:-1].ravel()).reshape(m, m)
+    for fix in (False, True):
+        eng = _make(N, N, n_para, h, 0.0, b0, fix_coarse_ascent=fix)
+        eng.presmooth()
+        err, total = 1.0, 0
+        while err > 1e-11 and total < 40000:
+            err = eng.cycles(500)[-1]
+            total += 500
+        x = _rows(eng, eng.x0)
+        rel = np.linalg.norm(x - x_direct) / np.linalg.norm(x_direct)
+        assert rel < 1e-10, (fix, total, err, rel)
+        eng.close()
+
+
+def test_rectangular_and_nan():
+    """Rectangular grids work; a NaN in the right-hand side surfaces in the returned norm."""
+    b = _rhs(129, 513, 5)
+    eng = _make(129, 513, 3, 0.1, 1e-3, b)
+    ref = oracle.GlobalSolver(129, 513, 3, 0.1, 1e-3)
+    ref.b[:] = b
+    assert eng.solve() == ref.solve()
+    assert eng.it == ref.it
+    b[40, 40] = np.nan
+    eng2 = _make(129, 513, 3, 0.1, 1e-3, b)
+    assert np.isnan(eng2.solve())
