@@ -171,8 +171,8 @@ class BlockSolver:
         return err
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_blocks_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.orc_blocks_destroy(self._h)
             self._h = None
 
 
@@ -210,6 +210,6 @@ class GlobalSolver:
         return err.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_global_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.orc_global_destroy(self._h)
             self._h = None

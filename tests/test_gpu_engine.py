@@ -80,8 +80,10 @@ def test_fix_coarse_ascent_equals_oracle():
 
 
 def _global_rhs_from_blocks(g, nsolve_index):
-    """The global right-hand side of solve number `nsolve_index` of a golden run: test.py mutates the
-    four blocks in place before every solve (test/test.py:77-78); stitch them as gather_blocks does."""
+    """The right-hand sides of solves 0..nsolve_index of a golden run, each as (global grid, the four
+    blocks).  test.py mutates the four blocks in place before every solve (test/test.py:77-78) -- from
+    the second mutation on the copies of a shared line in two blocks no longer agree, because a
+    block's first row is never updated -- and the global grid is their gather_blocks stitch."""
     n = int(g["n"])
     b0, h = (vortex_rhs if str(g["rhs"]) == "test" else main_rhs)(n)
     blocks = [np.zeros((2 ** n + 2, 2 ** n + 2)) for _ in range(4)]
@@ -95,7 +97,7 @@ def _global_rhs_from_blocks(g, nsolve_index):
                 blocks[k][:] /= 2
         full = np.zeros_like(b0)
         oracle.gather_blocks(blocks, full)
-        out.append(full)
+        out.append((full, [blk.copy() for blk in blocks]))
     return out, h
 
 
@@ -103,8 +105,12 @@ def _global_rhs_from_blocks(g, nsolve_index):
 # schedule; the reference's 4-block run deviates from that by its one-exchange-old corner halo cell
 # at the point where the blocks meet, which matters more the fewer cells a block has on its
 # coarsest Jacobi level (deep n_para on a small grid) and when the source sits on the junction.
+# For the two "m_" runs the source is a single Gaussian centred exactly on that junction: there the
+# reference's first cycles differ from the undecomposed schedule by tens of per cent (its four
+# copies of the centre point disagree with each other), the histories meet again within 2 % after
+# a few cycles, and the solutions agree to 1e-4; only the last cycle is compared for them.
 HISTORY_CASES = [("t_n8_p4", 1e-4), ("t_n7_p4", 1e-4), ("t_n6_p3", 1e-4), ("t_n6_p5", 5e-3), ("t_n5_p4", 1e-2),
-                 ("t_n5_p2", 1e-3), ("t_n4_p3", 1e-2), ("m_n5_p2", 0.4), ("m_n6_p3", 0.4)]
+                 ("t_n5_p2", 1e-3), ("t_n4_p3", 1e-2), ("m_n5_p2", None), ("m_n6_p3", None)]
 
 
 @pytest.mark.parametrize("name,tol", HISTORY_CASES, ids=lambda v: str(v))
@@ -120,28 +126,30 @@ def test_history_matches_reference_runs(name, tol):
     N = 2 ** (n + 1) + 1
     rhs, h = _global_rhs_from_blocks(g, int(g["nsolves"]) - 1)
     blk = oracle.BlockSolver(n, n_para, h, float(g["eps"]))
-    eng = _make(N, N, n_para, h, float(g["eps"]), rhs[0])
+    eng = _make(N, N, n_para, h, float(g["eps"]), rhs[0][0])
     pos = 0
     for s in range(int(g["nsolves"])):
         for k in range(4):
-            oracle.split(rhs[s], blk.b[k], k)
+            blk.b[k][:] = rhs[s][1][k]
         blk.solve()
         it_ref = int(g["its"][0][s])
         assert blk.it == it_ref and np.array_equal(blk.err_hist, g["err_cycle"][:, pos : pos + it_ref])
         pos += it_ref
-        eng.set_b_rows(torch.from_numpy(rhs[s]).cuda())
+        eng.set_b_rows(torch.from_numpy(rhs[s][0]).cuda())
         eng.presmooth()
         hist = np.array(eng.cycles(it_ref))
         rel = np.abs(hist - blk.interior_hist) / blk.interior_hist
-        assert rel.max() < tol, (s, rel)
-        # reduction per V-cycle (what the 5 % criterion is about)
-        if tol <= 1e-2:
-            ratio = (hist[1:] / hist[:-1]) / (blk.interior_hist[1:] / blk.interior_hist[:-1])
-            assert np.all(np.abs(ratio - 1) < 0.05)
         xg = np.zeros((N, N))
         oracle.gather_blocks(blk.x, xg)
-        x = _rows(eng, eng.x0)
-        assert np.linalg.norm(x - xg) / np.linalg.norm(xg) < max(tol, 1e-4) * 0.1
+        xrel = np.linalg.norm(_rows(eng, eng.x0) - xg) / np.linalg.norm(xg)
+        if tol is None:
+            assert rel[-1] < 0.02 and xrel < 1e-3, (s, rel, xrel)
+            continue
+        assert rel.max() < tol, (s, rel)
+        assert xrel < max(tol, 1e-4) * 0.1, (s, xrel)
+        # reduction per V-cycle: the 5 % criterion, met with a wide margin
+        ratio = (hist[1:] / hist[:-1]) / (blk.interior_hist[1:] / blk.interior_hist[:-1])
+        assert np.all(np.abs(ratio - 1) < 0.05)
 
 
 def test_solve_counts_cycles_like_the_reference():
@@ -150,10 +158,10 @@ def test_solve_counts_cycles_like_the_reference():
     import torch
     g = np.load(os.path.join(GOLDEN, "solve_t_n8_p4.npz"))
     rhs, h = _global_rhs_from_blocks(g, 1)
-    eng = _make(513, 513, 4, h, 0.025, rhs[0])
+    eng = _make(513, 513, 4, h, 0.025, rhs[0][0])
     errs = []
     for s in range(2):
-        eng.set_b_rows(torch.from_numpy(rhs[s]).cuda())
+        eng.set_b_rows(torch.from_numpy(rhs[s][0]).cuda())
         errs.append(eng.solve())
         assert eng.it == int(g["its"][0][s])
         assert abs(errs[-1] - g["errs"][:, s].max()) / errs[-1] < 1e-4
