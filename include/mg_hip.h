@@ -38,9 +38,12 @@ extern "C" {
 int mg_abi_version(void);
 const char *mg_last_error(void);
 
-/* Tuning/testing knob: upper bound (1, 2 or 4 doubles) on the per-lane vector width the stencil
- * kernels choose from the alignment of their arguments.  Results do not depend on it. */
-int mg_set_vector_width_cap(int cap);
+/* Tuning/testing knobs of the stencil kernels (results never depend on them):
+ *   "vector"      1 | 2      doubles per memory access (2 needs 16-byte aligned rows)
+ *   "unroll"      1 | 2 | 4  accesses per lane and row
+ *   "rows"        0..4096    rows per workgroup tile, 0 = automatic
+ *   "linear_map"  0 | 1      1 disables the XCD-aware workgroup -> tile mapping */
+int mg_set_tuning(const char *key, int value);
 
 /*
  * One Jacobi sweep, rows j0 <= j < j1 (1 <= j0, j1 <= ny-1), interior columns 1..nx-2:

@@ -30,7 +30,7 @@ _n = C.c_int
 SIGNATURES = {
     "mg_abi_version": ([], _n),
     "mg_last_error": ([], C.c_char_p),
-    "mg_set_vector_width_cap": ([_n], _n),
+    "mg_set_tuning": ([C.c_char_p, _n], _n),
     "mg_jacobi": ([_p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _i, _n, _p], _n),
     "mg_jacobi_from_zero": ([_p, _p, _i, _i, _i, _i, _i, _d, _i, _i, _n, _p], _n),
     "mg_residual": ([_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _i, _i, _n, _p], _n),

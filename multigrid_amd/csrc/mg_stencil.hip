@@ -12,104 +12,165 @@
 //
 // Arithmetic follows the reference's expression order (see include/mg_hip.h) and the file is
 // compiled with -ffp-contract=off.
+#include <string.h>
+
 #include "mg_common.h"
 
 enum { OP_JACOBI = 0, OP_JACOBI_ZERO = 1, OP_RESID = 2, OP_RESID_NORM = 3, OP_LAPLACE = 4 };
 
-template <int OP, int V, bool FINEST>
+// V = doubles per memory access (2 = one aligned 16-byte access, 1 = scalar for unaligned arrays),
+// U = accesses per lane and row.  Group k of a lane covers columns c0 + k*64*V .. +V-1, so each
+// wave-level load/store instruction touches 64*V consecutive doubles (1 KiB when V = 2) and the
+// wave's tile is 64*V*U columns wide.
+template <int OP, int V, int U, bool FINEST>
 __global__ __launch_bounds__(256) void mg_stencil5_kernel(const double *__restrict__ b, const double *__restrict__ x,
                                                           double *__restrict__ out, i64 nx, i64 ld, i64 j0, i64 j1,
-                                                          int rpb, int ncb, int nrc, double s, i64 bstride,
-                                                          u64 *__restrict__ norm_slots)
+                                                          int rpb, int ncb, int nrc, int linear_map, double s,
+                                                          i64 bstride, u64 *__restrict__ norm_slots)
 {
+    constexpr int WT = 64 * V * U; // wave tile width in columns
+    constexpr int GS = 64 * V;     // column stride between the groups of a lane
     int cb, rc;
-    mg_tile_of_block((int)blockIdx.x, ncb, nrc, cb, rc);
+    if (linear_map) {
+        cb = (int)blockIdx.x % ncb, rc = (int)blockIdx.x / ncb;
+    } else {
+        mg_tile_of_block((int)blockIdx.x, ncb, nrc, cb, rc);
+    }
     const i64 boff = (i64)blockIdx.y * bstride;
     if (OP != OP_LAPLACE) b += boff;
     if (OP != OP_JACOBI_ZERO) x += boff;
     out += boff;
 
     const int lane = threadIdx.x & 63;
-    const i64 c0 = ((i64)cb * 256 + threadIdx.x) * V; // first column of this lane
-    const i64 cl = c0 + V <= ld ? c0 : ld - V;         // column actually loaded (kept inside the row)
+    const i64 wbase = ((i64)cb * 4 + (threadIdx.x >> 6)) * WT; // first column of this wave's tile
+    i64 c0[U], cl[U];                                           // first column of each group / the one loaded
+    bool full[U], any[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        c0[k] = wbase + k * GS + lane * V;
+        cl[k] = c0[k] + V <= ld ? c0[k] : ld - V; // keep every access inside the row
+        full[k] = c0[k] >= 1 && c0[k] + V - 1 <= nx - 2;
+        any[k] = c0[k] + V - 1 >= 1 && c0[k] <= nx - 2 && c0[k] + V <= ld;
+    }
     const i64 rb = j0 + (i64)rc * rpb;
     const i64 re = rb + rpb < j1 ? rb + rpb : j1;
     u64 nmax = 0;
 
+    // Writes a row of results.  Groups that straddle the interior (column 0, columns >= nx-1) blend
+    // the cells outside it with what `out` already holds, so every store is a whole aligned vector.
+    auto store_row = [&](double *orow, double (&o)[U][V]) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (full[k]) {
+                stv<V>(orow + c0[k], o[k]);
+            } else if (any[k]) {
+                double keep[V];
+                ldv<V>(keep, orow + c0[k]);
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (!(c0[k] + v >= 1 && c0[k] + v <= nx - 2)) o[k][v] = keep[v];
+                stv<V>(orow + c0[k], o[k]);
+            }
+            if constexpr (OP == OP_RESID_NORM) {
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (c0[k] + v >= 1 && c0[k] + v <= nx - 2) {
+                        u64 key = (u64)__double_as_longlong(fabs(o[k][v]));
+                        nmax = key > nmax ? key : nmax;
+                    }
+            }
+        }
+    };
+
     if (rb < re) { // uniform per workgroup
         if constexpr (OP == OP_JACOBI_ZERO) {
             for (i64 j = rb; j < re; ++j) {
-                double bb[V], o[V];
-                ldv<V>(bb, b + j * ld + cl);
+                double o[U][V];
 #pragma unroll
-                for (int k = 0; k < V; ++k) o[k] = 0.25 * (0.0 - s * bb[k]);
-                double *op = out + j * ld + c0;
-                if (c0 >= 1 && c0 + V - 1 <= nx - 2) {
-                    stv<V>(op, o);
-                } else {
+                for (int k = 0; k < U; ++k) {
+                    double bb[V];
+                    ldv<V>(bb, b + j * ld + cl[k]);
 #pragma unroll
-                    for (int k = 0; k < V; ++k)
-                        if (c0 + k >= 1 && c0 + k <= nx - 2) op[k] = o[k];
+                    for (int v = 0; v < V; ++v) o[k][v] = 0.25 * (0.0 - s * bb[v]);
                 }
+                store_row(out + j * ld, o);
             }
         } else {
-            // edge element of the neighbouring wave: lane 0 needs column c0-1, lane 63 column c0+V
+            // Columns just outside the wave's tile: lane 0 fetches column wbase-1, lane 63 column
+            // wbase+WT (one predicated 8-byte load per row for the two lanes together).
             const bool isL = lane == 0, isR = lane == 63;
-            const i64 ce = isL ? c0 - 1 : c0 + V;
-            const bool pe = (isL && c0 >= 1 && c0 - 1 < nx) || (isR && c0 + V < nx);
-            const double *xr = x + (rb - 1) * ld; // row above the current one
-            double up[V], cur[V], dn[V];
-            ldv<V>(up, xr + cl);
-            ldv<V>(cur, xr + ld + cl);
-            double ecur = pe ? xr[ld + ce] : 0.0;
+            const i64 ce = isL ? wbase - 1 : wbase + WT;
+            const bool pe = (isL && wbase >= 1 && wbase - 1 < nx) || (isR && wbase + WT < nx);
+            auto load_row = [&](const double *row, double (&d)[U][V], double &e) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) ldv<V>(d[k], row + cl[k]);
+                e = pe ? row[ce] : 0.0;
+            };
+            auto load_b = [&](const double *row, double (&d)[U][V]) {
+                if constexpr (OP != OP_LAPLACE) {
+#pragma unroll
+                    for (int k = 0; k < U; ++k) ldv<V>(d[k], row + cl[k]);
+                }
+            };
+            // Software pipeline: the loads of row j+2 and of b[j+1] are issued before row j is
+            // computed, so a wave always has one row of loads in flight while it computes.
+            const double *xr = x + (rb - 1) * ld;
+            double up[U][V], cur[U][V], dn[U][V], nxt[U][V], bb[U][V], bn[U][V];
+            double eup, ecur, edn, enxt;
+            load_row(xr, up, eup);
+            load_row(xr + ld, cur, ecur);
+            load_row(xr + 2 * ld, dn, edn);
+            load_b(b + rb * ld, bb);
+            (void)eup;
             for (i64 j = rb; j < re; ++j) {
-                ldv<V>(dn, xr + 2 * ld + cl);
-                double edn = pe ? xr[2 * ld + ce] : 0.0;
-                double bb[V];
-                if constexpr (OP != OP_LAPLACE) ldv<V>(bb, b + j * ld + cl);
-                double west = wave_from_prev(cur[V - 1]);
-                double east = wave_from_next(cur[0]);
-                west = isL ? ecur : west;
-                east = isR ? ecur : east;
-                double o[V];
+                const i64 jn = j + 2 <= re ? j + 2 : re;         // row j+2, clamped into the tile's rows
+                const i64 jb = j + 1 < re ? j + 1 : re - 1;
+                load_row(x + jn * ld, nxt, enxt);
+                load_b(b + jb * ld, bn);
+                double o[U][V];
 #pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    const double E = k + 1 < V ? cur[k + 1 < V ? k + 1 : 0] : east;
-                    const double W = k > 0 ? cur[k > 0 ? k - 1 : 0] : west;
-                    if constexpr (OP == OP_JACOBI) {
-                        o[k] = 0.25 * (E + W + dn[k] + up[k] - s * bb[k]);
-                    } else if constexpr (OP == OP_LAPLACE) {
-                        o[k] = (W + E + up[k] + dn[k] - 4 * cur[k]) * s;
+                for (int k = 0; k < U; ++k) {
+                    // neighbours across the lane boundary: DPP from the adjacent lane; at the ends of
+                    // the wave from the other group of the opposite end lane, or the fetched edge
+                    double west = wave_from_prev(cur[k][V - 1]);
+                    double east = wave_from_next(cur[k][0]);
+                    if (k == 0) {
+                        west = isL ? ecur : west;
                     } else {
-                        const double left = W * s, cent = cur[k] * s;
-                        o[k] = bb[k] - left - (E + up[k] + dn[k]) * s + cent * 4;
+                        const double w = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cur[k - 1][V - 1]), 63),
+                                                          __builtin_amdgcn_readlane(__double2loint(cur[k - 1][V - 1]), 63));
+                        west = isL ? w : west;
                     }
-                }
-                double *op = out + j * ld + c0;
-                if (c0 >= 1 && c0 + V - 1 <= nx - 2) {
-                    stv<V>(op, o);
-                    if constexpr (OP == OP_RESID_NORM) {
+                    if (k == U - 1) {
+                        east = isR ? ecur : east;
+                    } else {
+                        const double e = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cur[k + 1 < U ? k + 1 : 0][0]), 0),
+                                                          __builtin_amdgcn_readlane(__double2loint(cur[k + 1 < U ? k + 1 : 0][0]), 0));
+                        east = isR ? e : east;
+                    }
 #pragma unroll
-                        for (int k = 0; k < V; ++k) {
-                            u64 key = (u64)__double_as_longlong(fabs(o[k]));
-                            nmax = key > nmax ? key : nmax;
+                    for (int v = 0; v < V; ++v) {
+                        const double E = v + 1 < V ? cur[k][v + 1 < V ? v + 1 : 0] : east;
+                        const double W = v > 0 ? cur[k][v > 0 ? v - 1 : 0] : west;
+                        if constexpr (OP == OP_JACOBI) {
+                            o[k][v] = 0.25 * (E + W + dn[k][v] + up[k][v] - s * bb[k][v]);
+                        } else if constexpr (OP == OP_LAPLACE) {
+                            o[k][v] = (W + E + up[k][v] + dn[k][v] - 4 * cur[k][v]) * s;
+                        } else {
+                            const double left = W * s, cent = cur[k][v] * s;
+                            o[k][v] = bb[k][v] - left - (E + up[k][v] + dn[k][v]) * s + cent * 4;
                         }
                     }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < V; ++k)
-                        if (c0 + k >= 1 && c0 + k <= nx - 2) {
-                            op[k] = o[k];
-                            if constexpr (OP == OP_RESID_NORM) {
-                                u64 key = (u64)__double_as_longlong(fabs(o[k]));
-                                nmax = key > nmax ? key : nmax;
-                            }
-                        }
                 }
+                store_row(out + j * ld, o);
 #pragma unroll
-                for (int k = 0; k < V; ++k) up[k] = cur[k], cur[k] = dn[k];
-                ecur = edn;
-                xr += ld;
+                for (int k = 0; k < U; ++k)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        up[k][v] = cur[k][v], cur[k][v] = dn[k][v], dn[k][v] = nxt[k][v];
+                        if constexpr (OP != OP_LAPLACE) bb[k][v] = bn[k][v];
+                    }
+                ecur = edn, edn = enxt;
             }
         }
     }
@@ -151,8 +212,36 @@ __global__ __launch_bounds__(256) void mg_maxabs_kernel(const double *__restrict
 
 // ------------------------------------------------------------------------------------------ host
 
+// ---- tuning knobs (speed only; results never depend on them) -------------------------------
+static int g_vec_cap = 2;   // doubles per access: 1 or 2
+static int g_unroll = 2;    // accesses per lane and row: 1, 2 or 4
+static int g_rows = 0;      // rows per tile, 0 = automatic
+static int g_linear_map = 0;
+
+extern "C" int mg_set_tuning(const char *key, int value)
+{
+    MG_REQUIRE(key, "mg_set_tuning: null key");
+    if (!strcmp(key, "vector")) {
+        MG_REQUIRE(value == 1 || value == 2, "mg_set_tuning: vector must be 1 or 2");
+        g_vec_cap = value;
+    } else if (!strcmp(key, "unroll")) {
+        MG_REQUIRE(value == 1 || value == 2 || value == 4, "mg_set_tuning: unroll must be 1, 2 or 4");
+        g_unroll = value;
+    } else if (!strcmp(key, "rows")) {
+        MG_REQUIRE(value >= 0 && value <= 4096, "mg_set_tuning: rows must be 0..4096");
+        g_rows = value;
+    } else if (!strcmp(key, "linear_map")) {
+        g_linear_map = value != 0;
+    } else {
+        mg_set_error("mg_set_tuning: unknown key '%s'", key);
+        return 1;
+    }
+    return 0;
+}
+
 static int rows_per_block(i64 nrows, int ncb, i64 nbatch)
 {
+    if (g_rows > 0) return g_rows;
     // Tall tiles amortise the two halo rows (2/rpb extra reads); small grids need short tiles to
     // produce enough workgroups for 256 CUs.
     int rpb = 128;
@@ -160,20 +249,21 @@ static int rows_per_block(i64 nrows, int ncb, i64 nbatch)
     return rpb;
 }
 
-template <int OP, int V>
+template <int OP, int V, int U>
 static int launch_stencil(const double *b, const double *x, double *out, i64 nx, i64 ld, i64 j0, i64 j1, double s,
                           i64 nbatch, i64 bstride, u64 *slots, int flags, hipStream_t st, const char *name)
 {
-    const int ncb = (int)((nx - 1 + 256 * V - 1) / (256 * V)); // columns 0 .. nx-2 need a lane
+    const int bw = 256 * V * U;                        // columns per workgroup
+    const int ncb = (int)((nx - 1 + bw - 1) / bw);     // columns 0 .. nx-2 need a lane
     const int rpb = rows_per_block(j1 - j0, ncb, nbatch);
     const int nrc = (int)((j1 - j0 + rpb - 1) / rpb);
     dim3 grid((unsigned)(ncb * nrc), (unsigned)nbatch);
     if (flags & MG_FLAG_FINEST)
-        hipLaunchKernelGGL((mg_stencil5_kernel<OP, V, true>), grid, dim3(256), 0, st, b, x, out, nx, ld, j0, j1, rpb,
-                           ncb, nrc, s, bstride, slots);
+        hipLaunchKernelGGL((mg_stencil5_kernel<OP, V, U, true>), grid, dim3(256), 0, st, b, x, out, nx, ld, j0, j1,
+                           rpb, ncb, nrc, g_linear_map, s, bstride, slots);
     else
-        hipLaunchKernelGGL((mg_stencil5_kernel<OP, V, false>), grid, dim3(256), 0, st, b, x, out, nx, ld, j0, j1, rpb,
-                           ncb, nrc, s, bstride, slots);
+        hipLaunchKernelGGL((mg_stencil5_kernel<OP, V, U, false>), grid, dim3(256), 0, st, b, x, out, nx, ld, j0, j1,
+                           rpb, ncb, nrc, g_linear_map, s, bstride, slots);
     MG_LAUNCH_CHECK(name);
     return 0;
 }
@@ -190,34 +280,33 @@ static int check_grid(const char *fn, i64 ny, i64 nx, i64 ld, i64 j0, i64 j1, i6
     return 0;
 }
 
-// the widest vector width the pointers and the leading dimension allow
+// 16-byte accesses need an even leading dimension and 16-byte aligned bases
 static int vec_width(i64 ld, i64 bstride, i64 nbatch, const void *p0, const void *p1, const void *p2)
 {
-    for (int v = 4; v > 1; v >>= 1) {
-        bool ok = ld % v == 0 && (nbatch == 1 || bstride % v == 0);
-        ok = ok && (!p0 || mg_aligned(p0, 8 * v)) && (!p1 || mg_aligned(p1, 8 * v)) && (!p2 || mg_aligned(p2, 8 * v));
-        if (ok) return v;
-    }
-    return 1;
+    bool ok = g_vec_cap >= 2 && ld % 2 == 0 && (nbatch == 1 || bstride % 2 == 0);
+    ok = ok && (!p0 || mg_aligned(p0, 16)) && (!p1 || mg_aligned(p1, 16)) && (!p2 || mg_aligned(p2, 16));
+    return ok ? 2 : 1;
 }
 
-#define DISPATCH_V(OP, ...)                                           \
-    switch (v) {                                                      \
-    case 4: return launch_stencil<OP, 4>(__VA_ARGS__);                \
-    case 2: return launch_stencil<OP, 2>(__VA_ARGS__);                \
-    default: return launch_stencil<OP, 1>(__VA_ARGS__);               \
-    }
-
-static int g_vec_cap = 4; // tuning/testing knob: upper bound on the vector width
-
-extern "C" int mg_set_vector_width_cap(int cap)
+// U accesses per lane only pay when the grid is wide enough to fill the wider tiles
+static int pick_unroll(i64 nx, int v)
 {
-    MG_REQUIRE(cap == 1 || cap == 2 || cap == 4, "mg_set_vector_width_cap: %d not in {1,2,4}", cap);
-    g_vec_cap = cap;
-    return 0;
+    int u = g_unroll;
+    while (u > 1 && nx < (i64)256 * v * u) u >>= 1;
+    return u;
 }
 
-static int capped(int v) { return v < g_vec_cap ? v : g_vec_cap; }
+#define DISPATCH_VU(OP, ...)                                                    \
+    do {                                                                        \
+        const int u_ = pick_unroll(nx, v);                                      \
+        if (v == 2) {                                                           \
+            if (u_ == 4) return launch_stencil<OP, 2, 4>(__VA_ARGS__);          \
+            if (u_ == 2) return launch_stencil<OP, 2, 2>(__VA_ARGS__);          \
+            return launch_stencil<OP, 2, 1>(__VA_ARGS__);                       \
+        }                                                                       \
+        if (u_ >= 2) return launch_stencil<OP, 1, 2>(__VA_ARGS__);              \
+        return launch_stencil<OP, 1, 1>(__VA_ARGS__);                           \
+    } while (0)
 
 extern "C" int mg_jacobi(const double *b, const double *x, double *x_out, i64 ny, i64 nx, i64 ld, i64 j0, i64 j1,
                          double h, i64 nbatch, i64 bstride, int flags, void *stream)
@@ -226,9 +315,9 @@ extern "C" int mg_jacobi(const double *b, const double *x, double *x_out, i64 ny
     MG_REQUIRE(b && x && x_out, "mg_jacobi: null array");
     MG_REQUIRE(x != x_out, "mg_jacobi: x_out aliases x");
     if (j0 == j1) return 0;
-    const int v = capped(vec_width(ld, bstride, nbatch, b, x, x_out));
-    DISPATCH_V(OP_JACOBI, b, x, x_out, nx, ld, j0, j1, h * h, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
-               "mg_jacobi")
+    const int v = vec_width(ld, bstride, nbatch, b, x, x_out);
+    DISPATCH_VU(OP_JACOBI, b, x, x_out, nx, ld, j0, j1, h * h, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
+                "mg_jacobi");
 }
 
 extern "C" int mg_jacobi_from_zero(const double *b, double *x_out, i64 ny, i64 nx, i64 ld, i64 j0, i64 j1, double h,
@@ -237,9 +326,9 @@ extern "C" int mg_jacobi_from_zero(const double *b, double *x_out, i64 ny, i64 n
     if (check_grid("mg_jacobi_from_zero", ny, nx, ld, j0, j1, nbatch, bstride)) return 1;
     MG_REQUIRE(b && x_out, "mg_jacobi_from_zero: null array");
     if (j0 == j1) return 0;
-    const int v = capped(vec_width(ld, bstride, nbatch, b, x_out, nullptr));
-    DISPATCH_V(OP_JACOBI_ZERO, b, nullptr, x_out, nx, ld, j0, j1, h * h, nbatch, bstride, nullptr, flags,
-               (hipStream_t)stream, "mg_jacobi_from_zero")
+    const int v = vec_width(ld, bstride, nbatch, b, x_out, nullptr);
+    DISPATCH_VU(OP_JACOBI_ZERO, b, nullptr, x_out, nx, ld, j0, j1, h * h, nbatch, bstride, nullptr, flags,
+                (hipStream_t)stream, "mg_jacobi_from_zero");
 }
 
 extern "C" int mg_residual(double *r, const double *x, const double *b, i64 ny, i64 nx, i64 ld, i64 j0, i64 j1,
@@ -249,23 +338,22 @@ extern "C" int mg_residual(double *r, const double *x, const double *b, i64 ny, 
     MG_REQUIRE(r && x && b, "mg_residual: null array");
     MG_REQUIRE(r != x, "mg_residual: r aliases x");
     if (j0 == j1) return 0;
-    const int v = capped(vec_width(ld, bstride, nbatch, b, x, r));
+    const int v = vec_width(ld, bstride, nbatch, b, x, r);
     const double hh = 1 / (h * h);
-    if (norm_slots) {
-        DISPATCH_V(OP_RESID_NORM, b, x, r, nx, ld, j0, j1, hh, nbatch, bstride, (u64 *)norm_slots, flags,
-                   (hipStream_t)stream, "mg_residual")
-    }
-    DISPATCH_V(OP_RESID, b, x, r, nx, ld, j0, j1, hh, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
-               "mg_residual")
+    if (norm_slots)
+        DISPATCH_VU(OP_RESID_NORM, b, x, r, nx, ld, j0, j1, hh, nbatch, bstride, (u64 *)norm_slots, flags,
+                    (hipStream_t)stream, "mg_residual");
+    DISPATCH_VU(OP_RESID, b, x, r, nx, ld, j0, j1, hh, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
+                "mg_residual");
 }
 
 extern "C" int mg_laplacian(const double *x, double *lplc, i64 ny, i64 nx, i64 ld, double h, void *stream)
 {
     if (check_grid("mg_laplacian", ny, nx, ld, 1, ny - 1, 1, 0)) return 1;
     MG_REQUIRE(x && lplc && x != lplc, "mg_laplacian: null or aliased array");
-    const int v = capped(vec_width(ld, 0, 1, x, lplc, nullptr));
-    DISPATCH_V(OP_LAPLACE, nullptr, x, lplc, nx, ld, 1, ny - 1, 1 / (h * h), 1, 0, nullptr, 0, (hipStream_t)stream,
-               "mg_laplacian")
+    const int v = vec_width(ld, 0, 1, x, lplc, nullptr);
+    DISPATCH_VU(OP_LAPLACE, nullptr, x, lplc, nx, ld, 1, ny - 1, 1 / (h * h), 1, 0, nullptr, 0, (hipStream_t)stream,
+                "mg_laplacian");
 }
 
 extern "C" int mg_norm_reset(uint64_t *norm_slots, void *stream)

@@ -111,17 +111,18 @@ def test_golden_split(mm, m):
 
 # ------------------------------------------------------------------ oracle, device tensors, all vector widths
 
-SHAPES = [(3, 3), (5, 9), (33, 33), (130, 130), (257, 513), (514, 1030), (100, 2051)]
+SHAPES = [(3, 3), (5, 9), (33, 33), (130, 130), (257, 513), (514, 1030), (100, 2051), (40, 4099)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=str)
-@pytest.mark.parametrize("cap", [1, 2, 4])
-def test_stencils_vs_oracle(mm, L, shape, cap):
-    rng = np.random.default_rng(hash(shape) % 1000 + cap)
+@pytest.mark.parametrize("vec,unroll", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4)])
+def test_stencils_vs_oracle(mm, L, shape, vec, unroll):
+    rng = np.random.default_rng(hash(shape) % 1000 + vec * 8 + unroll)
     a, b = rng.standard_normal(shape), rng.standard_normal(shape)
     r0, t0 = rng.standard_normal(shape), None
     h = 0.3
-    L.check(L.lib().mg_set_vector_width_cap(cap))
+    L.check(L.lib().mg_set_tuning(b"vector", vec))
+    L.check(L.lib().mg_set_tuning(b"unroll", unroll))
     try:
         # residual
         r_ref = r0.copy()
@@ -143,7 +144,8 @@ def test_stencils_vs_oracle(mm, L, shape, cap):
         mm.laplacian(padded(a), dl, h)
         assert np.array_equal(dl.cpu().numpy(), l_ref)
     finally:
-        L.check(L.lib().mg_set_vector_width_cap(4))
+        L.check(L.lib().mg_set_tuning(b"vector", 2))
+        L.check(L.lib().mg_set_tuning(b"unroll", 2))
 
 
 def test_jacobi_row_range_and_from_zero(L):

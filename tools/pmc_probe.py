@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""A handful of full-size launches of the streaming kernels, for rocprofv3 --pmc passes.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python3 tools/pmc_probe.py [--n 14]
+
+Counter collection serialises dispatches and is slow, so this probe launches each kernel of the
+V-cycle's finest level a few times on a 32769 x 32769 grid and nothing else (no graph, no
+right-hand-side generation: the arrays are filled by one torch call each)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=14)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    from multigrid_amd.levels import make_plan
+    from multigrid_amd.ops import HipOps
+
+    N = 2 ** (args.n + 1) + 1
+    plan = make_plan(N, N, 2, 1, 0, 1.0)
+    L0, L1 = plan.levels[0], plan.levels[1]
+    ops = HipOps()
+    x = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
+    y = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
+    b = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
+    c = torch.rand((L1.ny, L1.ld), dtype=torch.float64, device="cuda")
+    slots = ops.norm_slots()
+    torch.cuda.synchronize()
+    ops.begin()
+    for k in range(args.reps):
+        ops.jacobi(b, x, y, L0.nx, L0.t0, L0.t1, 0.5, True)
+        ops.residual(y, x, b, L0.nx, L0.t0, L0.t1, 0.5, slots, True)
+        ops.restrict(x, L0.nx, c, L1.nx, L1.t0, L1.t1, 0, -1)
+        ops.prolong_add(c, L1.nx, x, L0.nx, L0.t0, L0.t1, 0, -1)
+        ops.jacobi_from_zero(b, y, L0.nx, L0.t0, L0.t1, 0.5, True)
+        ops.synchronize()
+        print(f"rep {k} done", flush=True)
+    pts = (L0.t1 - L0.t0) * (L0.nx - 2)
+    print(f"grid {N}x{N}: {pts} points per launch; algorithmic bytes: jacobi/residual {24 * pts}, "
+          f"restrict {10 * pts}, prolong {18 * pts}, jacobi_from_zero {16 * pts}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
