@@ -141,6 +141,15 @@ int mg_sor(const double *b, double *x, double *r, int64_t ny, int64_t nx, int64_
  */
 int mg_copy2d(double *dst, int64_t dld, const double *src, int64_t sld, int64_t ny, int64_t nx, void *stream);
 
+/*
+ * Halo exchange of the reference's four 2x2 block ranks, for all four at once: v holds the four
+ * (m x m) blocks of one variable bstride elements apart (rank order 0..3), stage is scratch of
+ * 8*m doubles.  Replaces Buffers.exchange_buffers, core/parallel_multigrid.py:83-97 (pack all,
+ * then unpack east/west before north/south; corner cells included, as the reference moves whole
+ * lines).  Used by the block-layout drop-in Multigrid; the slab engine exchanges rows instead.
+ */
+int mg_block_exchange(double *v, int64_t m, int64_t ld, int64_t bstride, double *stage, void *stream);
+
 /* a[0:n] = 0.0 (the `x[:] = 0` of core/parallel_multigrid.py:276,291,295), as a memset node. */
 int mg_zero(double *a, int64_t n, void *stream);
 

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mg_prolong_add": ([_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _n),
     "mg_sor": ([_p, _p, _p, _i, _i, _i, _d, _i, _n, _n, _i, _i, _p], _n),
     "mg_copy2d": ([_p, _i, _p, _i, _i, _i, _p], _n),
+    "mg_block_exchange": ([_p, _i, _i, _i, _p, _p], _n),
     "mg_zero": ([_p, _i, _p], _n),
     "mg_split": ([_p, _i, _i, _i, _p, _i, _i, _i, _p], _n),
     "mg_graph_begin": ([_p], _n),

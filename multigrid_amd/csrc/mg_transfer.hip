@@ -223,6 +223,52 @@ extern "C" int mg_copy2d(double *dst, i64 dld, const double *src, i64 sld, i64 n
     return 0;
 }
 
+// ------------------------------------------------------------------------------- 2x2 block halo exchange
+
+// The reference's halo exchange for its four block ranks, executed for all four at once
+// (Buffers.exchange_buffers, core/parallel_multigrid.py:19-97, width = 1, overlap = 1).
+// Directions: 0 east, 1 west, 2 north (+rows), 3 south.  Every rank first packs the line just
+// inside the shared centre line (:39-42), then unpacks into its outermost line (:44-47), east/west
+// before north/south as its `neighbours` dict is ordered (:49-56) -- the order decides which
+// message a halo corner cell ends up with.  One workgroup: the three phases are separated by
+// workgroup barriers.
+__global__ __launch_bounds__(1024) void mg_block_exchange_kernel(double *v, i64 m, i64 ld, i64 bs, double *stage)
+{
+    const int dirs[4][2] = {{0, 2}, {1, 2}, {0, 3}, {1, 3}};
+    const int peers[4][2] = {{1, 2}, {0, 3}, {3, 0}, {2, 1}};
+    for (i64 idx = threadIdx.x; idx < 8 * m; idx += blockDim.x) {
+        const int rk = (int)(idx / (2 * m)), q = (int)((idx / m) & 1);
+        const i64 k = idx % m;
+        const double *a = v + rk * bs;
+        const int d = dirs[rk][q];
+        stage[idx] = d == 0 ? a[k * ld + (m - 3)] : d == 1 ? a[k * ld + 2] : d == 2 ? a[(m - 3) * ld + k] : a[2 * ld + k];
+    }
+    for (int q = 0; q < 2; ++q) {
+        __syncthreads();
+        for (i64 idx = threadIdx.x; idx < 4 * m; idx += blockDim.x) {
+            const int rk = (int)(idx / m);
+            const i64 k = idx % m;
+            double *a = v + rk * bs;
+            const int d = dirs[rk][q];
+            const double val = stage[(peers[rk][q] * 2 + q) * m + k]; // the peer's message of the same axis
+            if (d == 0) a[k * ld + (m - 1)] = val;
+            else if (d == 1) a[k * ld] = val;
+            else if (d == 2) a[(m - 1) * ld + k] = val;
+            else a[k] = val;
+        }
+    }
+}
+
+extern "C" int mg_block_exchange(double *v, i64 m, i64 ld, i64 bstride, double *stage, void *stream)
+{
+    MG_REQUIRE(v && stage, "mg_block_exchange: null array");
+    MG_REQUIRE(m >= 4 && ld >= m && bstride >= m * ld, "mg_block_exchange: bad shape (side %lld, ld %lld, stride %lld)",
+               (long long)m, (long long)ld, (long long)bstride);
+    hipLaunchKernelGGL(mg_block_exchange_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, m, ld, bstride, stage);
+    MG_LAUNCH_CHECK("mg_block_exchange");
+    return 0;
+}
+
 extern "C" int mg_zero(double *a, i64 n, void *stream)
 {
     MG_REQUIRE(a && n >= 0, "mg_zero: bad argument");

@@ -1,0 +1,107 @@
+"""The drop-in `parallel_multigrid` surface on the GPU against the reference's own runs.
+
+`Multigrid` (block layout) must reproduce tests/golden/solve_*.npz -- produced by the reference's
+Python on four ranks -- bit for bit: iteration counts, every per-cycle per-rank error, the returned
+errors and the x / r blocks of every rank, warm-started repeat solves included.  The test reads
+like the reference's driver (test/test.py:33-87), one rank after the other.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.rhs import main_rhs
+from tests.rhs import test_rhs as vortex_rhs
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+SOLVES = sorted(glob.glob(os.path.join(GOLDEN, "solve_*.npz")))
+
+
+@pytest.mark.parametrize("path", SOLVES, ids=lambda p: os.path.basename(p)[6:-4])
+def test_block_multigrid_reproduces_reference_runs(path):
+    from multigrid_amd.parallel_multigrid import BlockWorld, Multigrid, gather_blocks, split
+    g = np.load(path)
+    n, n_para = int(g["n"]), int(g["n_para"])
+    b0, h = (vortex_rhs if str(g["rhs"]) == "test" else main_rhs)(n)
+    nx1 = 2 ** n + 1
+    world = BlockWorld()
+    world.verbose = False
+    b, a, R, solvers = [], [], [], []
+    for rank in range(4):
+        bk = np.zeros((nx1 + 1, nx1 + 1))
+        split(b0, bk, rank)
+        b.append(bk)
+        a.append(np.zeros_like(bk))
+        R.append(np.zeros_like(bk))
+        solvers.append(Multigrid(bk, a[-1], R[-1], h, float(g["eps"]), n, n_para, rank=rank, world=world))
+    its, errs, hist = [], [], []
+    for _ in range(int(g["nsolves"])):
+        if int(g["mutate"]):
+            for rank in range(4):  # test/test.py:77-78
+                b[rank][1:-1] += b[rank][0:-2]
+                b[rank][:] /= 2
+        errs.append([solvers[rank].solve() for rank in range(4)])
+        its.append([solvers[rank].it for rank in range(4)])
+        hist += world.err_history
+    assert np.array_equal(np.array(its).T, g["its"])
+    assert np.array_equal(np.array(errs).T, g["errs"])
+    assert np.array_equal(np.array(hist).T, g["err_cycle"])
+    if "x0" in g:
+        for rank in range(4):
+            assert np.array_equal(a[rank], g[f"x{rank}"])
+            assert np.array_equal(R[rank], g[f"r{rank}"])
+        for i in range(len(solvers[0].x_wl)):
+            assert np.array_equal(solvers[0].x_wl[i], g[f"x_wl{i}"])
+            assert np.array_equal(solvers[2].r_wl[i], g[f"r_wl{i}"])
+            assert np.array_equal(solvers[1].b_wl[i], g[f"b_wl{i}"])
+    else:
+        for rank in range(4):
+            assert np.array_equal(a[rank][::8, ::8], g[f"x{rank}_s8"])
+            assert np.array_equal(R[rank][::8, ::8], g[f"r{rank}_s8"])
+            assert float(np.sum(a[rank])) == float(g[f"x{rank}_sum"])
+    # gather_blocks: from the four blocks, and from one rank's array through the world
+    full = np.zeros_like(b0)
+    gather_blocks(world, a, full)
+    full2 = np.zeros_like(b0)
+    gather_blocks(world, a[2], full2)
+    nx2 = nx1
+    assert np.array_equal(full[:nx2, :nx2], a[0][:-1, :-1]) and np.array_equal(full[nx2:, nx2:], a[3][2:, 2:])
+    assert np.array_equal(full[:nx2, nx2:], a[1][:-1, 2:]) and np.array_equal(full[nx2:, :nx2], a[2][2:, :-1])
+    assert np.array_equal(full, full2)
+
+
+def test_multigrid_argument_checks():
+    from multigrid_amd.parallel_multigrid import BlockWorld, Multigrid, MgError, offsets
+    w = BlockWorld()
+    z = np.zeros((34, 34))
+    with pytest.raises(AssertionError):
+        Multigrid(z, z.copy(), z.copy(), 1.0, 0.1, 4, 2, rank=0, world=w)   # nx != 2**n + 2
+    with pytest.raises(AssertionError):
+        Multigrid(z, z.copy(), z.copy(), 1.0, 0.1, 5, 5, rank=0, world=w)   # n_para < n
+    with pytest.raises(TypeError):
+        Multigrid(z.astype(np.float32), z.copy(), z.copy(), 1.0, 0.1, 5, 2, rank=0, world=w)
+    m = Multigrid(z, z.copy(), z.copy(), 1.0, 0.1, 5, 2, rank=0, world=w)
+    with pytest.raises(MgError):
+        m.solve()  # collective: the other three ranks are missing
+    assert [len(m.x_sb), len(m.b_sb), len(m.x_wl)] == [2, 3, 4] and m.h_wl == [4.0, 8.0, 16.0, 32.0]
+    assert offsets(3) == {"j": -1, "i": -1}
+
+
+def test_global_multigrid_aliases_caller_arrays():
+    import oracle
+    from multigrid_amd.parallel_multigrid import GlobalMultigrid
+    n, n_para = 6, 3
+    b0, h = vortex_rhs(n)
+    x, r = np.zeros_like(b0), np.zeros_like(b0)
+    mg = GlobalMultigrid(b0, x, r, h, 0.025, n, n_para)
+    err = mg.solve()
+    ref = oracle.GlobalSolver(*b0.shape, n_para, h, 0.025)
+    ref.b[:] = b0
+    assert err == ref.solve() and mg.it == ref.it
+    assert np.array_equal(x, ref.x) and np.array_equal(r, ref.r)
+    b0 *= 0.5  # the caller mutates the right-hand side in place; the next solve sees it (warm start)
+    ref.b[:] = b0
+    assert mg.solve() == ref.solve() and mg.it == ref.it
+    assert np.array_equal(x, ref.x)

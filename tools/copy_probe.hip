@@ -1,0 +1,76 @@
+// Streaming-bandwidth probe for MI355X: what do plain copy / 2-read-1-write kernels reach with
+// (a) linear grid-stride access and (b) the column-strip row-marching access of the stencil kernels?
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/copy_probe tools/copy_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef long long i64;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <bool NT>
+__global__ __launch_bounds__(256) void copy_gs(const double2* __restrict__ a, double2* __restrict__ o, i64 n2) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n2; i += (i64)gridDim.x * 256) {
+    if (NT) { double2 v; v.x = __builtin_nontemporal_load(&a[i].x); v.y = __builtin_nontemporal_load(&a[i].y);
+              __builtin_nontemporal_store(v.x, &o[i].x); __builtin_nontemporal_store(v.y, &o[i].y); }
+    else o[i] = a[i];
+  }
+}
+// each block copies a contiguous chunk (block-linear), 4 loads in flight per thread
+__global__ __launch_bounds__(256) void copy_chunk(const double2* __restrict__ a, double2* __restrict__ o, i64 n2, i64 per_block) {
+  i64 b0 = (i64)blockIdx.x * per_block, b1 = b0 + per_block < n2 ? b0 + per_block : n2;
+  for (i64 i = b0 + threadIdx.x; i < b1; i += 1024) {
+    double2 v0 = a[i], v1 = i + 256 < b1 ? a[i + 256] : v0, v2 = i + 512 < b1 ? a[i + 512] : v0, v3 = i + 768 < b1 ? a[i + 768] : v0;
+    o[i] = v0; if (i + 256 < b1) o[i + 256] = v1; if (i + 512 < b1) o[i + 512] = v2; if (i + 768 < b1) o[i + 768] = v3;
+  }
+}
+__global__ __launch_bounds__(256) void add_gs(const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ o, i64 n2) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n2; i += (i64)gridDim.x * 256) {
+    double2 x = a[i], y = b[i]; o[i] = make_double2(x.x + y.x, x.y + y.y);
+  }
+}
+// column strips: block = 512 columns x rpb rows, marching down rows (like the stencil kernels)
+__global__ __launch_bounds__(256) void add_tile(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o,
+                                                i64 ld, int rpb, int ncb) {
+  int cb = blockIdx.x % ncb, rc = blockIdx.x / ncb;
+  i64 c = ((i64)cb * 256 + threadIdx.x) * 2;
+  for (i64 j = (i64)rc * rpb; j < (i64)(rc + 1) * rpb; ++j) {
+    double2 x = *(const double2*)(a + j * ld + c), y = *(const double2*)(b + j * ld + c);
+    *(double2*)(o + j * ld + c) = make_double2(x.x + y.x, x.y + y.y);
+  }
+}
+int main(int argc, char** argv) {
+  i64 ny = 32768, ld = 32768 + 16;
+  i64 n = ny * ld, n2 = n / 2;
+  double *a, *b, *o;
+  CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc(&o, n * 8));
+  CK(hipMemset(a, 1, n * 8)); CK(hipMemset(b, 2, n * 8)); CK(hipMemset(o, 0, n * 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto report = [&](const char* name, double bytes, auto launch) {
+    launch(); CK(hipDeviceSynchronize());
+    float best = 1e9, tot = 0; int reps = 5;
+    for (int r = 0; r < reps; ++r) { CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms; if (ms < best) best = ms; }
+    printf("%-28s avg %7.3f ms  %7.0f GB/s   best %7.0f GB/s\n", name, tot / reps, bytes / (tot / reps) / 1e6, bytes / best / 1e6); fflush(stdout);
+  };
+  for (int blocks : {2048, 4096, 8192, 65536}) {
+    char nm[64]; snprintf(nm, 64, "copy_gs blocks=%d", blocks);
+    report(nm, 2.0 * n * 8, [&] { hipLaunchKernelGGL(copy_gs<false>, dim3(blocks), dim3(256), 0, 0, (const double2*)a, (double2*)o, n2); });
+  }
+  report("copy_gs_nt blocks=4096", 2.0 * n * 8, [&] { hipLaunchKernelGGL(copy_gs<true>, dim3(4096), dim3(256), 0, 0, (const double2*)a, (double2*)o, n2); });
+  for (int blocks : {2048, 8192, 32768}) {
+    char nm[64]; snprintf(nm, 64, "copy_chunk blocks=%d", blocks);
+    i64 per = (n2 + blocks - 1) / blocks; per = (per + 1023) / 1024 * 1024;
+    report(nm, 2.0 * n * 8, [&] { hipLaunchKernelGGL(copy_chunk, dim3(blocks), dim3(256), 0, 0, (const double2*)a, (double2*)o, n2, per); });
+  }
+  report("memcpyDtoD", 2.0 * n * 8, [&] { CK(hipMemcpyAsync(o, a, n * 8, hipMemcpyDeviceToDevice, 0)); });
+  for (int blocks : {2048, 8192})  {
+    char nm[64]; snprintf(nm, 64, "add_gs (2R1W) blocks=%d", blocks);
+    report(nm, 3.0 * n * 8, [&] { hipLaunchKernelGGL(add_gs, dim3(blocks), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (double2*)o, n2); });
+  }
+  for (int rpb : {32, 128, 512}) {
+    char nm[64]; snprintf(nm, 64, "add_tile (2R1W) rpb=%d", rpb);
+    int ncb = 32768 / 512;
+    report(nm, 3.0 * ny * 32768 * 8, [&] { hipLaunchKernelGGL(add_tile, dim3(ncb * (ny / rpb)), dim3(256), 0, 0, a, b, o, ld, rpb, ncb); });
+  }
+  return 0;
+}
