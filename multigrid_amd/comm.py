@@ -1,0 +1,85 @@
+"""Rank-to-rank data movement of the slab engine over torch.distributed.
+
+`SlabComm` wraps the four patterns the V-cycle needs -- neighbour row exchange, gather of the
+staging level to rank 0, scatter of the correction, max-reduction of the residual norm -- for two
+situations:
+
+* direct: the tensors can be handed to the backend as they are (CUDA tensors on `nccl`, which is
+  RCCL on ROCm and moves the rows over xGMI; or CPU tensors on `gloo` in the host-only tests);
+* staged: CUDA tensors on a `gloo` group.  Every message goes through a host copy.  Slow, but it
+  lets several ranks share ONE GPU, which is how the multi-rank path is rehearsed on a single-GPU
+  machine (RCCL refuses two ranks on one device).
+"""
+import torch
+import torch.distributed as dist
+
+
+class SlabComm:
+    def __init__(self, ops, group=None, world=1, rank=0):
+        self.ops, self.group, self.world, self.rank = ops, group, world, rank
+        self.staged = False
+        if world > 1:
+            backend = dist.get_backend(group)
+            self.staged = backend == "gloo" and ops.name == "hip"
+            # one collective up front: every rank joins the communicator before the first
+            # point-to-point batch (the backends create their channels lazily)
+            t = ops.zeros(1, 1)
+            self.allreduce_max(t.view(-1))
+
+    def _peer(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def sendrecv(self, sends, recvs):
+        """sends/recvs: lists of (1-D tensor view, group rank).  All of them form one batch."""
+        if not sends and not recvs:
+            return
+        with self.ops.ctx():
+            if not self.staged:
+                ops_ = [dist.P2POp(dist.isend, t, self._peer(p), self.group) for t, p in sends]
+                ops_ += [dist.P2POp(dist.irecv, t, self._peer(p), self.group) for t, p in recvs]
+                for w in dist.batch_isend_irecv(ops_):
+                    w.wait()
+                return
+            host_s = [(t.cpu(), p) for t, p in sends]  # .cpu() waits for the kernels that produced the rows
+            host_r = [(torch.empty(t.shape, dtype=t.dtype), p, t) for t, p in recvs]
+            ops_ = [dist.P2POp(dist.isend, h, self._peer(p), self.group) for h, p in host_s]
+            ops_ += [dist.P2POp(dist.irecv, h, self._peer(p), self.group) for h, p, _ in host_r]
+            for w in dist.batch_isend_irecv(ops_):
+                w.wait()
+            for h, _, t in host_r:
+                t.copy_(h)
+
+    def gather0(self, src, parts):
+        """Every rank contributes `src`; rank 0 receives them into the list `parts` (else None)."""
+        with self.ops.ctx():
+            if not self.staged:
+                dist.gather(src, parts, dst=self._peer(0), group=self.group)
+                return
+            h = src.cpu()
+            hp = [torch.empty_like(h) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(h, hp, dst=self._peer(0), group=self.group)
+            if self.rank == 0:
+                for d, s in zip(parts, hp):
+                    d.copy_(s)
+
+    def scatter0(self, dst, parts):
+        """Rank 0 sends parts[k] to rank k; every rank receives into `dst`."""
+        with self.ops.ctx():
+            if not self.staged:
+                dist.scatter(dst, parts, src=self._peer(0), group=self.group)
+                return
+            h = torch.empty(dst.shape, dtype=dst.dtype)
+            hp = [p.cpu() for p in parts] if self.rank == 0 else None
+            dist.scatter(h, hp, src=self._peer(0), group=self.group)
+            dst.copy_(h)
+
+    def allreduce_max(self, t):
+        """In-place MAX over ranks of a small NaN-free tensor; returns it."""
+        with self.ops.ctx():
+            if not self.staged:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                return t
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(h)
+            return t

@@ -26,6 +26,7 @@ the C ABI) and a torch.distributed process group for the exchanges.
 import torch
 import torch.distributed as dist
 
+from .comm import SlabComm
 from .levels import make_plan
 
 
@@ -45,6 +46,7 @@ class SlabMultigrid:
             world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
             rank = dist.get_rank(group) if world > 1 else 0
         self.world, self.rank = world, rank
+        self.comm = SlabComm(ops, group, world, rank)
         self.plan = make_plan(gny, gnx, n_para, world, rank, h0)
         self.n_para = n_para
         self.epsilon = epsilon
@@ -138,24 +140,18 @@ class SlabMultigrid:
         if self.world == 1:
             return
         R, nx = L.rows, L.nx
-        ops_ = []
+        sends, recvs = [], []
         if self.rank > 0:
             if down:  # the rank above needs my first owned row as its lower halo
-                ops_.append(dist.P2POp(dist.isend, arr[1, :nx], self._peer(self.rank - 1), self.group))
+                sends.append((arr[1, :nx], self.rank - 1))
             if up:
-                ops_.append(dist.P2POp(dist.irecv, arr[0, :nx], self._peer(self.rank - 1), self.group))
+                recvs.append((arr[0, :nx], self.rank - 1))
         if self.rank < self.world - 1:
             if up:    # the rank below needs my last owned row as its upper halo
-                ops_.append(dist.P2POp(dist.isend, arr[R, :nx], self._peer(self.rank + 1), self.group))
+                sends.append((arr[R, :nx], self.rank + 1))
             if down:
-                ops_.append(dist.P2POp(dist.irecv, arr[R + 1, :nx], self._peer(self.rank + 1), self.group))
-        if ops_:
-            with self.ops.ctx():
-                for w in dist.batch_isend_irecv(ops_):
-                    w.wait()
-
-    def _peer(self, r):
-        return r if self.group is None else dist.get_global_rank(self.group, r)
+                recvs.append((arr[R + 1, :nx], self.rank + 1))
+        self.comm.sendrecv(sends, recvs)
 
     # ------------------------------------------------------------------ building blocks
     def _jacobi_sweeps(self, l, src, dst, n, finest=False):
@@ -203,24 +199,25 @@ class SlabMultigrid:
         if self.world == 1:
             self._run_tail()
             return self._xw0_slab
-        with o.ctx():
-            stage = self.b[self.n_para]
-            if self.rank == 0:
-                parts = list(self._gather_buf.view(self.world, S.ny, S.ld).unbind(0))
-                dist.gather(stage, parts, dst=self._peer(0), group=self.group)
-                R = S.rows
+        stage = self.b[self.n_para]
+        if self.rank == 0:
+            parts = list(self._gather_buf.view(self.world, S.ny, S.ld).unbind(0))
+            self.comm.gather0(stage, parts)
+            R = S.rows
+            with o.ctx():
                 g = self._gather_buf.view(self.world, S.ny, S.ld)
                 # owned rows of every rank, in order; the last global row is boundary (stays zero)
                 self.bw[0][: self.world * R].view(self.world, R, S.ld).copy_(g[:, 1 : R + 1, :])
-                self._run_tail()
+            self._run_tail()
+            with o.ctx():
                 # rank p gets global rows p*R-1 .. (p+1)*R of the correction = padded rows p*R .. p*R+R+1
                 win = self._xw0_pad.as_strided((self.world, S.ny, S.ld), (R * S.ld, S.ld, 1))
                 self._scatter_buf.view(self.world, S.ny, S.ld).copy_(win)
-                parts = list(self._scatter_buf.view(self.world, S.ny, S.ld).unbind(0))
-                dist.scatter(stage, parts, src=self._peer(0), group=self.group)
-            else:
-                dist.gather(stage, None, dst=self._peer(0), group=self.group)
-                dist.scatter(stage, None, src=self._peer(0), group=self.group)
+            parts = list(self._scatter_buf.view(self.world, S.ny, S.ld).unbind(0))
+            self.comm.scatter0(stage, parts)
+        else:
+            self.comm.gather0(stage, None)
+            self.comm.scatter0(stage, None)
         return stage
 
     def _run_tail(self):
@@ -287,9 +284,13 @@ class SlabMultigrid:
         if self.world == 1:
             return self.ops.norm_read(self.norm)
         with self.ops.ctx():
-            t = self.ops.norm_tensor(self.norm)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            return float(t.item())
+            v = self.ops.norm_tensor(self.norm)
+            # a NaN on any rank must win, whatever the backend's max does with NaNs
+            t = torch.cat([torch.nan_to_num(v, nan=0.0), torch.isnan(v).to(v.dtype)])
+        t = self.comm.allreduce_max(t)
+        with self.ops.ctx():
+            vals = t.tolist()
+        return float("nan") if vals[1] > 0 else float(vals[0])
 
     def cycles(self, k):
         """Run exactly k V-cycles (no stop test); returns max|r| after each."""

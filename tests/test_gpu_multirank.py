@@ -1,0 +1,75 @@
+"""Several ranks sharing ONE GPU (gloo group, messages staged through the host): the multi-rank
+schedule of the slab engine with the real HIP kernels, streams and the rank-0 tail graph.  Results
+must equal the single-rank engine / the undecomposed oracle bit for bit.  Marked gpu."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multigrid_amd.engine import SlabMultigrid
+        eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank)
+        assert eng.comm.staged
+        R = eng.plan.levels[0].rows
+        a, e = eng.owned_rows()
+        eng.set_b_rows(torch.from_numpy(b[rank * R : rank * R + (e - a)]).cuda())
+        eng.presmooth()
+        errs = eng.cycles(cycles)
+        x = eng.local_rows(eng.x0).cpu().numpy()
+        r = eng.local_rows(eng.r0).cpu().numpy()
+        q.put((rank, errs, x, r))
+        dist.barrier()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,gny,gnx,n_para", [(2, 257, 257, 3), (4, 1025, 513, 5)], ids=str)
+def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para):
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal((gny, gnx))
+    b[0] = b[-1] = 0
+    b[:, 0] = b[:, -1] = 0
+    h, cycles = 0.37, 3
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0)
+    ref.b[:] = b
+    ref.solve(ncycles=cycles)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        rank, errs, x, r = q.get(timeout=280)
+        out[rank] = (errs, x, r)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in range(world):
+        assert out[k][0] == ref.err_hist.tolist()
+    assert np.array_equal(np.concatenate([out[k][1] for k in range(world)]), ref.x)
+    assert np.array_equal(np.concatenate([out[k][2] for k in range(world)]), ref.r)
