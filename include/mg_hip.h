@@ -115,6 +115,28 @@ int mg_prolong_add(const double *crs, int64_t cny, int64_t cnx, int64_t cld, dou
                    void *stream);
 
 /*
+ * One fused smoothing pass (temporal blocking): in a single pass over memory
+ *     [x_in += prolongation(crs)]  ->  `sweeps` (1..3) Jacobi sweeps  ->  [residual of the result]
+ * with  x_in == NULL : start from x = 0 (the zeroed x of core/parallel_multigrid.py:276),
+ *       crs  != NULL : bilinear prolongation of crs added first (mg_prolong_add with ofst_i = 0),
+ *       r    != NULL : r = b - laplacian(x_out) on the interior cells of rows j0..j1-1 (+ max-norm
+ *                      into norm_slots when that is non-NULL, as mg_residual).
+ * Produces rows j0 <= j < j1 of x_out (and r); reads rows j0-D .. j1+D-1 of x_in and b, D = sweeps
+ * (+1 with r), so those must be valid (halo rows included).  Rows <= fix_lo and >= fix_hi and the
+ * columns 0 and nx-1 are Dirichlet cells: their values pass through unchanged.  x_out's cells
+ * outside rows j0..j1-1 are not written.  Bit-identical to the same sequence of mg_prolong_add,
+ * mg_jacobi and mg_residual calls (smooth_parallel, core/parallel_multigrid.py:100-114, with the
+ * preceding interpolate_add_to, :309/:322), but x and b are read once and x written once.
+ * Needs 16-byte aligned arrays with an even ld.
+ */
+int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
+                    int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld, int64_t j0,
+                    int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps, double h,
+                    uint64_t *norm_slots, void *stream);
+/* Tuning knobs of mg_smooth_fused: column pairs per lane (1 or 2), rows per tile (0 = automatic). */
+int mg_set_fused_tuning(int unroll, int rows);
+
+/*
  * Coarse-grid smoother: `iterations` x (forward sweep [+ backward sweep]) of SOR with omega = 1.5,
  *     x[j,i] = (1-w)*x[j,i] + (w/4)*(x[j,i+1] + x[j,i-1] + x[j+1,i] + x[j-1,i] - h*h*b[j,i]),
  * in place, followed by the residual (as mg_residual) into r when r != NULL.

@@ -1,0 +1,368 @@
+// Fused smoothing passes of the V-cycle on gfx950 (temporal blocking).
+//
+// One launch performs, on a whole level and in ONE pass over memory,
+//     [x += prolongation(coarse)]  ->  K Jacobi sweeps  ->  [residual (+ max-norm)]
+// so that x and b are read once and x (and r) written once for K sweeps, instead of once per
+// sweep: K = 3 with both ends fused moves 26-32 B per point where the separate kernels move
+// 90-96 B.  Results are bit-identical to the separate kernels: every point value is computed by
+// the same expression from the same operands, only earlier.
+//
+// How: a wave owns a strip of W = 128*U columns and streams down the rows.  It keeps, per stage
+// s = 0..D-1 (D = K, +1 with the residual), a three-row register window of stage-s values; when
+// input row i arrives, stage 1 can produce row i-1, stage 2 row i-2, ... stage K row i-K, the
+// residual row i-K-1.  Sideways, the values a stage needs from the neighbouring lane come by DPP
+// (v_readlane across the seam between a lane's column groups), and what lies beyond the strip is
+// simply not available: validity shrinks by one column per stage from both strip edges, so strips
+// overlap by 2*Dv columns (Dv = D rounded up to even, keeping every owned range aligned to the
+// 16-byte column pairs) and a strip stores only the columns it owns.  Dirichlet boundary cells are
+// passed through every stage unchanged, so validity does not shrink from a fixed boundary.
+// The same shrinking applies to rows: a tile producing rows [rb, re) streams rows rb-D .. re+D-1.
+// Redundant work: 2*Dv/W of the columns (3 % for D = 4, U = 2) and 2*D/rpb of the rows.
+//
+// Arithmetic follows the reference's expression order (see include/mg_hip.h); compiled with
+// -ffp-contract=off.
+#include "mg_common.h"
+
+struct FusedArgs {
+    const double *b;     // right-hand side of the level
+    const double *xin;   // current x (unused when ZERO)
+    double *xout;        // x after K sweeps (must not alias xin)
+    double *r;           // residual (RESID)
+    const double *crs;   // coarse x to prolong and add before the sweeps (PROLONG)
+    i64 ny, nx, ld, cny, cnx, cld;
+    i64 j0, j1;          // rows to produce
+    i64 flo, fhi;        // rows <= flo and >= fhi are fixed (Dirichlet): passed through
+    int rpb, ncb, nrc, ntc, oj;
+    double h2, hh;
+    u64 *norm;
+};
+
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+template <int K, bool PROLONG, bool ZERO, bool RESID, int U>
+__global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
+{
+    constexpr int D = K + (RESID ? 1 : 0);
+    constexpr int Dv = (D + 1) & ~1;
+    constexpr int W = 128 * U;
+    constexpr int STRIDE = W - 2 * Dv;
+    int cb, rc;
+    mg_tile_of_block((int)blockIdx.x, a.ncb, a.nrc, cb, rc);
+    const int lane = threadIdx.x & 63;
+    const int tile = cb * 4 + (threadIdx.x >> 6);
+    const bool active = tile < a.ntc;
+    const i64 origin = (i64)(active ? tile : 0) * STRIDE;
+    const i64 own_lo = tile == 0 ? 0 : origin + Dv;
+    const i64 own_hi = origin + W - 1 >= a.nx - 1 ? ((a.nx - 1) | 1) : origin + W - 1 - Dv;
+    const i64 nx = a.nx, ld = a.ld;
+    const bool isR = lane == 63;
+
+    i64 c0[U], cl[U];
+    bool st[U], ic[U][2];
+#pragma unroll
+    for (int g = 0; g < U; ++g) {
+        c0[g] = origin + g * 128 + 2 * lane;
+        cl[g] = c0[g] + 2 <= ld ? c0[g] : ld - 2;
+        st[g] = active && c0[g] >= own_lo && c0[g] + 1 <= own_hi && c0[g] + 2 <= ld;
+        ic[g][0] = c0[g] >= 1 && c0[g] <= nx - 2;
+        ic[g][1] = c0[g] + 1 >= 1 && c0[g] + 1 <= nx - 2;
+    }
+    const i64 rb = a.j0 + (i64)rc * a.rpb;
+    const i64 re = rb + a.rpb < a.j1 ? rb + a.rpb : a.j1;
+    u64 nmax = 0;
+
+    if (active && rb < re) { // uniform per wave
+        double w[D][3][U][2]; // w[s]: stage-s values of three consecutive rows (oldest first)
+        double br[D][U][2];   // br[d]: b of row i-1-d
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int g = 0; g < U; ++g) w[s][q][g][0] = w[s][q][g][1] = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int g = 0; g < U; ++g) br[d][g][0] = br[d][g][1] = 0.0;
+
+        auto rowclamp = [&](i64 j) { return j < 0 ? (i64)0 : (j > a.ny - 1 ? a.ny - 1 : j); };
+        auto load_pairs = [&](const double *base, i64 j, double (&d)[U][2]) {
+            const double *row = base + rowclamp(j) * ld;
+#pragma unroll
+            for (int g = 0; g < U; ++g) {
+                double2 t = *reinterpret_cast<const double2 *>(row + cl[g]);
+                d[g][0] = t.x, d[g][1] = t.y;
+            }
+        };
+        // coarse row J: value at coarse column c0/2 and at the next coarse column
+        auto load_coarse = [&](i64 J, double (&v0)[U], double (&v1)[U]) {
+            const i64 Jc = J < 0 ? 0 : (J > a.cny - 1 ? a.cny - 1 : J);
+            const double *row = a.crs + Jc * a.cld;
+#pragma unroll
+            for (int g = 0; g < U; ++g) {
+                const i64 q = c0[g] >> 1;
+                v0[g] = row[q > a.cnx - 1 ? a.cnx - 1 : q];
+            }
+#pragma unroll
+            for (int g = 0; g < U; ++g) {
+                double nb = wave_from_next(v0[g]);
+                if (g + 1 < U) {
+                    const double e = lane_bcast(v0[g + 1 < U ? g + 1 : 0], 0);
+                    nb = isR ? e : nb;
+                } else {
+                    const i64 q1 = (c0[g] >> 1) + 1;
+                    const double e = isR ? row[q1 > a.cnx - 1 ? a.cnx - 1 : q1] : 0.0;
+                    nb = isR ? e : nb;
+                }
+                v1[g] = nb;
+            }
+        };
+
+        const i64 i0 = rb - D, i1 = re + D; // input rows streamed: i0 .. i1-1 (clamped into the array)
+        double xn[U][2], bn[U][2];          // prefetched: x row i, b row i-1
+        if constexpr (!ZERO) load_pairs(a.xin, i0, xn);
+        load_pairs(a.b, i0 - 1, bn);
+        // coarse rows for the prolongation: cA = row J, cB = row J+1 of the current fine row
+        double cA0[U], cA1[U], cB0[U], cB1[U], cN0[U], cN1[U];
+        i64 Jh = 0;
+        if constexpr (PROLONG) {
+            Jh = (rowclamp(i0) - a.oj) >> 1;
+            load_coarse(Jh, cA0, cA1);
+            load_coarse(Jh + 1, cB0, cB1);
+#pragma unroll
+            for (int g = 0; g < U; ++g) cN0[g] = cB0[g], cN1[g] = cB1[g];
+        }
+
+        for (i64 i = i0; i < i1; ++i) {
+            // ---- take the prefetched rows, issue the loads of the next step
+            double y0[U][2], bcur[U][2];
+#pragma unroll
+            for (int g = 0; g < U; ++g) {
+                y0[g][0] = ZERO ? 0.0 : xn[g][0], y0[g][1] = ZERO ? 0.0 : xn[g][1];
+                bcur[g][0] = bn[g][0], bcur[g][1] = bn[g][1];
+            }
+            if constexpr (!ZERO) load_pairs(a.xin, i + 1, xn);
+            load_pairs(a.b, i, bn);
+            if constexpr (PROLONG) {
+                const i64 ic_ = rowclamp(i);
+                const i64 J = (ic_ - a.oj) >> 1;
+                if (J != Jh) { // uniform: at most one coarse row further
+#pragma unroll
+                    for (int g = 0; g < U; ++g) cA0[g] = cB0[g], cA1[g] = cB1[g], cB0[g] = cN0[g], cB1[g] = cN1[g];
+                    Jh = J;
+                }
+                const i64 Jn = (rowclamp(i + 1) - a.oj) >> 1;
+                if (Jn != Jh) load_coarse(Jn + 1, cN0, cN1); // needed from the next step on
+                if (i > a.flo && i < a.fhi && i >= 0 && i <= a.ny - 1) {
+                    const bool odd = (ic_ - a.oj) & 1;
+#pragma unroll
+                    for (int g = 0; g < U; ++g) {
+                        double add0, add1;
+                        if (odd) {
+                            add0 = (cA0[g] + cB0[g]) / 2;
+                            add1 = (cB1[g] + cB0[g] + cA1[g] + cA0[g]) / 4;
+                        } else {
+                            add0 = cA0[g];
+                            add1 = (cA0[g] + cA1[g]) / 2;
+                        }
+                        if (ic[g][0]) y0[g][0] += add0;
+                        if (ic[g][1]) y0[g][1] += add1;
+                    }
+                }
+            }
+            // ---- push stage 0 and b
+#pragma unroll
+            for (int g = 0; g < U; ++g)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    w[0][0][g][v] = w[0][1][g][v], w[0][1][g][v] = w[0][2][g][v], w[0][2][g][v] = y0[g][v];
+#pragma unroll
+                    for (int d = D - 1; d > 0; --d) br[d][g][v] = br[d - 1][g][v];
+                    br[0][g][v] = bcur[g][v];
+                }
+            // ---- stages 1..K: stage s produces row i-s from the stage s-1 window
+#pragma unroll
+            for (int s = 1; s <= K; ++s) {
+                const i64 row = i - s;
+                const bool rint = row > a.flo && row < a.fhi;
+                double o[U][2];
+#pragma unroll
+                for (int g = 0; g < U; ++g) {
+                    double west = wave_from_prev(w[s - 1][1][g][1]);
+                    double east = wave_from_next(w[s - 1][1][g][0]);
+                    if (g > 0) {
+                        const double t = lane_bcast(w[s - 1][1][g > 0 ? g - 1 : 0][1], 63);
+                        west = lane == 0 ? t : west;
+                    }
+                    if (g + 1 < U) {
+                        const double t = lane_bcast(w[s - 1][1][g + 1 < U ? g + 1 : 0][0], 0);
+                        east = isR ? t : east;
+                    }
+                    const double c0v = w[s - 1][1][g][0], c1v = w[s - 1][1][g][1];
+                    const double j0v = 0.25 * (c1v + west + w[s - 1][2][g][0] + w[s - 1][0][g][0] - a.h2 * br[s - 1][g][0]);
+                    const double j1v = 0.25 * (east + c0v + w[s - 1][2][g][1] + w[s - 1][0][g][1] - a.h2 * br[s - 1][g][1]);
+                    o[g][0] = (rint && ic[g][0]) ? j0v : c0v;
+                    o[g][1] = (rint && ic[g][1]) ? j1v : c1v;
+                }
+                if (s == K && row >= rb && row < re) {
+                    double *orow = a.xout + row * ld;
+#pragma unroll
+                    for (int g = 0; g < U; ++g)
+                        if (st[g]) *reinterpret_cast<double2 *>(orow + c0[g]) = make_double2(o[g][0], o[g][1]);
+                }
+                if (s < D) {
+#pragma unroll
+                    for (int g = 0; g < U; ++g)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v)
+                            w[s][0][g][v] = w[s][1][g][v], w[s][1][g][v] = w[s][2][g][v], w[s][2][g][v] = o[g][v];
+                }
+            }
+            // ---- residual of row i-K-1 from the stage-K window
+            if constexpr (RESID) {
+                const i64 row = i - K - 1;
+                if (row >= rb && row < re && row > a.flo && row < a.fhi) {
+                    double *rrow = a.r + row * ld;
+#pragma unroll
+                    for (int g = 0; g < U; ++g) {
+                        double west = wave_from_prev(w[K][1][g][1]);
+                        double east = wave_from_next(w[K][1][g][0]);
+                        if (g > 0) {
+                            const double t = lane_bcast(w[K][1][g > 0 ? g - 1 : 0][1], 63);
+                            west = lane == 0 ? t : west;
+                        }
+                        if (g + 1 < U) {
+                            const double t = lane_bcast(w[K][1][g + 1 < U ? g + 1 : 0][0], 0);
+                            east = isR ? t : east;
+                        }
+                        const double c0v = w[K][1][g][0], c1v = w[K][1][g][1];
+                        double r0 = br[K][g][0] - west * a.hh - (c1v + w[K][0][g][0] + w[K][2][g][0]) * a.hh + (c0v * a.hh) * 4;
+                        double r1 = br[K][g][1] - c0v * a.hh - (east + w[K][0][g][1] + w[K][2][g][1]) * a.hh + (c1v * a.hh) * 4;
+                        if (st[g]) {
+                            // cells outside the interior keep what r holds (the reference never writes them)
+                            if (!(ic[g][0] && ic[g][1])) {
+                                double2 keep = *reinterpret_cast<double2 *>(rrow + c0[g]);
+                                if (!ic[g][0]) r0 = keep.x;
+                                if (!ic[g][1]) r1 = keep.y;
+                            }
+                            *reinterpret_cast<double2 *>(rrow + c0[g]) = make_double2(r0, r1);
+                            if (ic[g][0]) {
+                                u64 key = (u64)__double_as_longlong(fabs(r0));
+                                nmax = key > nmax ? key : nmax;
+                            }
+                            if (ic[g][1]) {
+                                u64 key = (u64)__double_as_longlong(fabs(r1));
+                                nmax = key > nmax ? key : nmax;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (RESID) {
+        if (a.norm) { // uniform
+            __shared__ u64 wmax[4];
+            nmax = wave_max_u64(nmax);
+            if (lane == 0) wmax[threadIdx.x >> 6] = nmax;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u64 m = wmax[0];
+                for (int k = 1; k < 4; ++k) m = wmax[k] > m ? wmax[k] : m;
+                if (m) atomicMax(&a.norm[blockIdx.x % MG_NORM_SLOTS], m);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+
+static int g_fused_unroll = 2;
+static int g_fused_rows = 0;
+
+extern "C" int mg_set_fused_tuning(int unroll, int rows)
+{
+    MG_REQUIRE(unroll == 1 || unroll == 2, "mg_set_fused_tuning: unroll must be 1 or 2");
+    MG_REQUIRE(rows >= 0 && rows <= 8192, "mg_set_fused_tuning: rows must be 0..8192");
+    g_fused_unroll = unroll, g_fused_rows = rows;
+    return 0;
+}
+
+template <int K, bool PROLONG, bool ZERO, bool RESID, int U>
+static int launch_fused(FusedArgs a, hipStream_t st)
+{
+    constexpr int D = K + (RESID ? 1 : 0), Dv = (D + 1) & ~1, W = 128 * U, STRIDE = W - 2 * Dv;
+    a.ntc = a.nx <= W ? 1 : (int)((a.nx - W + STRIDE - 1) / STRIDE) + 1;
+    a.ncb = (a.ntc + 3) / 4;
+    int rpb = g_fused_rows;
+    if (rpb <= 0) {
+        rpb = 256;
+        while (rpb > 8 * D && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) < 2048) rpb >>= 1;
+    }
+    a.rpb = rpb;
+    a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
+    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, U>), dim3((unsigned)(a.ncb * a.nrc)), dim3(256), 0, st,
+                       a);
+    MG_LAUNCH_CHECK("mg_smooth_fused");
+    return 0;
+}
+
+template <int K, bool PROLONG, bool ZERO, bool RESID>
+static int pick_u(const FusedArgs &a, hipStream_t st)
+{
+    int u = g_fused_unroll;
+    while (u > 1 && a.nx < 128 * u) u >>= 1;
+    if (u == 2) return launch_fused<K, PROLONG, ZERO, RESID, 2>(a, st);
+    return launch_fused<K, PROLONG, ZERO, RESID, 1>(a, st);
+}
+
+template <int K>
+static int pick_mode(const FusedArgs &a, bool prolong, bool zero, bool resid, hipStream_t st)
+{
+    if (zero) return resid ? pick_u<K, false, true, true>(a, st) : pick_u<K, false, true, false>(a, st);
+    if (prolong) return resid ? pick_u<K, true, false, true>(a, st) : pick_u<K, true, false, false>(a, st);
+    return resid ? pick_u<K, false, false, true>(a, st) : pick_u<K, false, false, false>(a, st);
+}
+
+extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
+                               i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo,
+                               i64 fix_hi, i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, void *stream)
+{
+    MG_REQUIRE(b && x_out, "mg_smooth_fused: null array");
+    MG_REQUIRE(sweeps >= 1 && sweeps <= 3, "mg_smooth_fused: 1..3 sweeps per pass, got %d", sweeps);
+    MG_REQUIRE(ny >= 3 && nx >= 3 && ld >= nx, "mg_smooth_fused: bad shape");
+    MG_REQUIRE(ld % 2 == 0 && mg_aligned(b, 16) && mg_aligned(x_out, 16) && (!x_in || mg_aligned(x_in, 16)) &&
+                   (!r || mg_aligned(r, 16)),
+               "mg_smooth_fused: arrays must be 16-byte aligned with an even leading dimension");
+    MG_REQUIRE(j0 >= 0 && j1 <= ny && j0 <= j1, "mg_smooth_fused: row range [%lld, %lld) outside the array", (long long)j0,
+               (long long)j1);
+    MG_REQUIRE(x_in != x_out && r != x_out && (const double *)r != x_in, "mg_smooth_fused: aliased arrays");
+    MG_REQUIRE(nx < ((i64)1 << 30) && ny < ((i64)1 << 30), "mg_smooth_fused: grid side too large");
+    if (crs) {
+        MG_REQUIRE(x_in, "mg_smooth_fused: prolongation needs x_in");
+        MG_REQUIRE(cny >= 2 && cnx >= 2 && cld >= cnx, "mg_smooth_fused: bad coarse shape");
+        MG_REQUIRE(ofst_j == 0 || ofst_j == -1, "mg_smooth_fused: ofst_j must be 0 or -1");
+        // every interior fine cell must have its coarse cells: 1 <= t - ofst_j <= 2*cny-3, 1 <= c <= 2*cnx-3
+        MG_REQUIRE(fix_lo + 1 - ofst_j >= 1 && fix_hi - 1 - ofst_j <= 2 * cny - 3 && nx - 2 <= 2 * cnx - 3,
+                   "mg_smooth_fused: coarse grid %lld x %lld does not cover the fine interior", (long long)cny,
+                   (long long)cnx);
+    }
+    if (j0 == j1) return 0;
+    FusedArgs a;
+    a.b = b, a.xin = x_in, a.xout = x_out, a.r = r, a.crs = crs;
+    a.ny = ny, a.nx = nx, a.ld = ld, a.cny = cny, a.cnx = cnx, a.cld = cld;
+    a.j0 = j0, a.j1 = j1, a.flo = fix_lo, a.fhi = fix_hi, a.oj = (int)ofst_j;
+    a.h2 = h * h, a.hh = 1 / (h * h), a.norm = (u64 *)norm_slots;
+    a.rpb = a.ncb = a.nrc = a.ntc = 0;
+    const bool zero = x_in == nullptr, prolong = crs != nullptr, resid = r != nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    switch (sweeps) {
+    case 1: return pick_mode<1>(a, prolong, zero, resid, st);
+    case 2: return pick_mode<2>(a, prolong, zero, resid, st);
+    default: return pick_mode<3>(a, prolong, zero, resid, st);
+    }
+}

@@ -36,7 +36,7 @@ class SlabMultigrid:
 
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
-                 max_cycles=100, use_graph=True, overlap=True):
+                 max_cycles=100, use_graph=True, fused=True):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -54,7 +54,9 @@ class SlabMultigrid:
         self.fix_coarse_ascent = fix_coarse_ascent
         self.keep_ascent_residuals = keep_ascent_residuals
         self.max_cycles = max_cycles
-        self.overlap = overlap and world > 1
+        # fused multi-sweep passes need halos as deep as the fused depth; until the slab exchange
+        # moves that many rows they are used on one rank only (results are identical either way)
+        self.fused = fused and world == 1 and getattr(ops, "supports_fused", False)
         self.use_graph = use_graph and getattr(ops, "supports_graphs", False)
         self.it = 0
         self.err_history = []
@@ -163,11 +165,41 @@ class SlabMultigrid:
             src, dst = dst, src
         return src
 
-    def _smooth_level0(self, n, want_norm):
-        """smooth_parallel on the finest level: exchange, n sweeps, residual (:100-114)."""
+    @staticmethod
+    def _chunks(n, most=3):
+        """n sweeps as passes of at most `most` sweeps, as even as possible (6 -> 3+3, 4 -> 2+2)."""
+        k = (n + most - 1) // most
+        return [n // k + (1 if i < n % k else 0) for i in range(k)]
+
+    def _smooth_fused(self, l, src, crs, cnx, n, r=None, norm=None):
+        """[src += P(crs)], n Jacobi sweeps, [residual into r (+ norm)] on level l as fused passes that
+        ping-pong between the level's two x arrays.  src None = start from zero.  Returns the array
+        that holds the result."""
+        L, o = self.plan.levels[l], self.ops
+        xa, xb = self._xa[l], self._xb[l]
+        chunks = self._chunks(n)
+        for ci, k in enumerate(chunks):
+            dst = xa if (src is None or src is xb) else xb
+            last = ci == len(chunks) - 1
+            if last and norm is not None:
+                o.norm_reset(norm)
+            o.smooth_fused(self.b[l], src, dst, r if last else None, crs if ci == 0 else None, L.nx, cnx, L.t0, L.t1,
+                           L.t0 - 1, L.t1, -1, k, L.h, norm if last else None)
+            src = dst
+        return src
+
+    def _smooth_level0(self, n, want_norm, crs=None):
+        """smooth_parallel on the finest level: exchange, n sweeps, residual (:100-114); with `crs`
+        the preceding prolongation (:322) is part of it."""
         L, o = self.plan.levels[0], self.ops
         xs = [self._xa[0], self._xb[0]]
         cur = xs[self._cur0]
+        if self.fused:
+            res = self._smooth_fused(0, cur, crs, self.plan.levels[1].nx, n, self.r[0], self.norm if want_norm else None)
+            self._cur0 = 0 if res is xs[0] else 1
+            return
+        if crs is not None:
+            o.prolong_add(crs, self.plan.levels[1].nx, cur, L.nx, L.t0, L.t1, 0, -1)
         self._exchange(cur, L)
         res = self._jacobi_sweeps(0, cur, xs[1 - self._cur0], n, finest=True)
         self._cur0 = 0 if res is xs[0] else 1
@@ -240,6 +272,12 @@ class SlabMultigrid:
         for l in range(1, n_para):
             L = Ls[l]
             xa, xb = self._xa[l], self._xb[l]
+            if self.fused:  # x = 0, N1 sweeps and the residual in one pass (result must land in xa)
+                res = self._smooth_fused(l, None, None, 0, self.N1, self.r[l])
+                if res is not xa:
+                    o.copy_(xa, res)
+                o.restrict(self.r[l], L.nx, self.b[l + 1], Ls[l + 1].nx, Ls[l + 1].t0, Ls[l + 1].t1, 0, -1)
+                continue
             # x = 0 then N1 sweeps: the first sweep needs no x (all zeros), the rest ping-pong
             o.jacobi_from_zero(self.b[l], xa, L.nx, L.t0, L.t1, L.h)
             self._exchange(xa, L)
@@ -256,6 +294,12 @@ class SlabMultigrid:
             L = Ls[l]
             xa, xb = self._xa[l], self._xb[l]
             cnx = Ls[l + 1].nx
+            if self.fused:
+                res = self._smooth_fused(l, xa, corr, cnx, self.N2, self.r[l] if self.keep_ascent_residuals else None)
+                if res is not xa:
+                    o.copy_(xa, res)
+                corr = xa
+                continue
             o.prolong_add(corr, cnx, xa, L.nx, L.t0, L.t1, 0, -1)
             self._exchange(xa, L)
             res = self._jacobi_sweeps(l, xa, xb, self.N2)
@@ -263,9 +307,7 @@ class SlabMultigrid:
             if self.keep_ascent_residuals:
                 o.residual(self.r[l], xa, self.b[l], L.nx, L.t0, L.t1, L.h)
             corr = xa
-        cur = self.x0
-        o.prolong_add(corr, Ls[1].nx, cur, Ls[0].nx, Ls[0].t0, Ls[0].t1, 0, -1)
-        self._smooth_level0(self.N2, want_norm=True)
+        self._smooth_level0(self.N2, want_norm=True, crs=corr)
 
     # ------------------------------------------------------------------ drivers
     def _run_cycle(self):
@@ -275,7 +317,7 @@ class SlabMultigrid:
                 self.ops.graph_begin()
                 self._cycle()
                 self._graphs[key] = self.ops.graph_end()
-                assert self._cur0 == key  # N2 is even: the finest x returns to the same array
+                assert self._cur0 == key  # the finest x returns to the same array every cycle
             self.ops.graph_launch(self._graphs[key])
         else:
             self._cycle()

@@ -80,6 +80,17 @@ class HipOps:
         check(self.L.mg_prolong_add(c.data_ptr(), c.shape[0], cnx, c.stride(0), f.data_ptr(), f.shape[0], fnx,
                                     f.stride(0), t0, t1, 1, fnx - 2, oi, oj, 1, 0, 0, self._s))
 
+    supports_fused = True
+
+    def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None):
+        """[x_in += P(crs)] -> `sweeps` Jacobi sweeps -> [residual]; x_in None = start from zero."""
+        check(self.L.mg_smooth_fused(b.data_ptr(), x_in.data_ptr() if x_in is not None else None, x_out.data_ptr(),
+                                     r.data_ptr() if r is not None else None,
+                                     crs.data_ptr() if crs is not None else None, x_out.shape[0], nx, x_out.stride(0),
+                                     crs.shape[0] if crs is not None else 0, cnx,
+                                     crs.stride(0) if crs is not None else 0, j0, j1, fix_lo, fix_hi, oj, sweeps, h,
+                                     norm.data_ptr() if norm is not None else None, self._s))
+
     def sor(self, b, x, r, nx, h, iterations, ordering):
         check(self.L.mg_sor(b.data_ptr(), x.data_ptr(), r.data_ptr() if r is not None else None, x.shape[0], nx,
                             x.stride(0), h, iterations, 1,

@@ -79,6 +79,22 @@ class OracleOps:
         oracle.interpolate_add_to(np.ascontiguousarray(c.numpy()[:, :cnx]), fc, oi, oj)
         f.numpy()[t0:t1, 1 : fnx - 1] = fc[t0:t1, 1 : fnx - 1]
 
+    supports_fused = True
+
+    def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None):
+        """The fused pass as the sequence it stands for: prolong_add, `sweeps` Jacobi sweeps, residual
+        (rows between the fixed rows are the interior; only rows j0..j1-1 are written back)."""
+        cur = torch.zeros_like(x_out) if x_in is None else x_in.clone()
+        if crs is not None:
+            self.prolong_add(crs, cnx, cur, nx, fix_lo + 1, fix_hi, 0, oj)
+        for _ in range(sweeps):
+            nxt = cur.clone()
+            self.jacobi(b, cur, nxt, nx, fix_lo + 1, fix_hi, h)
+            cur = nxt
+        x_out[j0:j1] = cur[j0:j1]
+        if r is not None:
+            self.residual(r, cur, b, nx, j0, j1, h, norm)
+
     def sor(self, b, x, r, nx, h, iterations, ordering):
         xs = np.ascontiguousarray(x.numpy()[:, :nx])
         bs = np.ascontiguousarray(b.numpy()[:, :nx])

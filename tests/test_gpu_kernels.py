@@ -375,3 +375,96 @@ def test_error_behaviour(mm, L):
     o = np.full((5, 5), 3.0)
     mm.split(a, o, 7)
     assert np.all(o == 3.0)
+
+
+# ------------------------------------------------------------------ fused multi-sweep passes
+
+FUSED_SHAPES = [(9, 9), (40, 121), (70, 249), (66, 250), (300, 257), (130, 1000), (600, 2051), (35, 4099)]
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES, ids=str)
+@pytest.mark.parametrize("sweeps", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["plain", "zero", "prolong"])
+@pytest.mark.parametrize("resid", [False, True])
+@pytest.mark.parametrize("unroll", [1, 2])
+def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unroll):
+    """mg_smooth_fused == mg_prolong_add, `sweeps` x mg_jacobi, mg_residual, bit for bit (and hence
+    == the oracle, which the separate kernels are checked against above)."""
+    import ctypes as C
+    import torch
+    ny, nx = shape
+    rng = np.random.default_rng(ny * 131 + nx + sweeps)
+    h = 0.3
+    x = rng.standard_normal(shape)
+    b = rng.standard_normal(shape)
+    r0 = rng.standard_normal(shape)
+    if mode == "zero":
+        x[:] = 0
+    # slab convention: row 0 is a dummy, row 1 and row ny-1 are Dirichlet rows, fine row t <-> coarse (t+1)/2
+    flo, fhi, j0, j1 = 1, ny - 1, 2, ny - 1
+    R = ny - 2
+    cny, cnx = (R // 2 + 2 if R % 2 == 0 else 0), (nx - 1) // 2 + 1
+    prolong = mode == "prolong" and R % 2 == 0 and nx % 2 == 1
+    if mode == "prolong" and not prolong:
+        pytest.skip("no coarse grid for this shape")
+    c = rng.standard_normal((cny, cnx)) if prolong else None
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.mg_set_fused_tuning(unroll, 0))
+    db, dx = padded(b), padded(x)
+    ld = dx.stride(0)
+    dc = padded(c) if prolong else None
+    # reference sequence with the separate kernels
+    cur = padded(x)
+    if prolong:
+        L.check(lib.mg_prolong_add(dc.data_ptr(), cny, cnx, dc.stride(0), cur.data_ptr(), ny, nx, ld, j0, j1, 1, nx - 2,
+                                   0, -1, 1, 0, 0, st))
+    oth = cur.clone()
+    for _ in range(sweeps):
+        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, j0, j1, h, 1, 0, 0, st))
+        cur, oth = oth, cur
+    slots = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
+    r_ref = padded(r0)
+    nrm_ref = C.c_double()
+    if resid:
+        L.check(lib.mg_residual(r_ref.data_ptr(), cur.data_ptr(), db.data_ptr(), ny, nx, ld, j0, j1, h, slots.data_ptr(),
+                                1, 0, 0, st))
+        L.check(lib.mg_norm_read(slots.data_ptr(), C.byref(nrm_ref), st))
+    # fused
+    out = padded(x)  # boundary/fixed cells of the output array must already hold x's values
+    rr = padded(r0)
+    L.check(lib.mg_norm_reset(slots.data_ptr(), st))
+    L.check(lib.mg_smooth_fused(db.data_ptr(), None if mode == "zero" else dx.data_ptr(), out.data_ptr(),
+                                rr.data_ptr() if resid else None, dc.data_ptr() if prolong else None, ny, nx, ld,
+                                cny if prolong else 0, cnx if prolong else 0, dc.stride(0) if prolong else 0, j0, j1,
+                                flo, fhi, -1, sweeps, h, slots.data_ptr() if resid else None, st))
+    assert np.array_equal(out.cpu().numpy(), cur.cpu().numpy())
+    if resid:
+        nrm = C.c_double()
+        L.check(lib.mg_norm_read(slots.data_ptr(), C.byref(nrm), st))
+        assert np.array_equal(rr.cpu().numpy(), r_ref.cpu().numpy())
+        assert nrm.value == nrm_ref.value
+    L.check(lib.mg_set_fused_tuning(2, 0))
+
+
+def test_fused_pass_partial_rows(L):
+    """Producing only rows [j0, j1) needs valid input on D more rows each side and leaves the rest alone."""
+    import torch
+    rng = np.random.default_rng(77)
+    ny, nx, h = 200, 515, 0.4
+    x, b = rng.standard_normal((ny, nx)), rng.standard_normal((ny, nx))
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    db, dx = padded(b), padded(x)
+    ld = dx.stride(0)
+    cur, oth = padded(x), padded(x)
+    for _ in range(3):
+        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, 1, ny - 1, h, 1, 0, 0, st))
+        cur, oth = oth, cur
+    out = padded(np.full((ny, nx), 5.0))
+    L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), out.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, 60, 131, 0,
+                                ny - 1, 0, 3, h, None, st))
+    got, ref = out.cpu().numpy(), cur.cpu().numpy()
+    assert np.array_equal(got[60:131], ref[60:131])
+    got[60:131] = 5.0
+    assert np.all(got == 5.0)
