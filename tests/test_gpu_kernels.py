@@ -419,7 +419,7 @@ def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unrol
     if prolong:
         L.check(lib.mg_prolong_add(dc.data_ptr(), cny, cnx, dc.stride(0), cur.data_ptr(), ny, nx, ld, j0, j1, 1, nx - 2,
                                    0, -1, 1, 0, 0, st))
-    oth = cur.clone()
+    oth = padded(cur.cpu().numpy())
     for _ in range(sweeps):
         L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, j0, j1, h, 1, 0, 0, st))
         cur, oth = oth, cur
