@@ -340,7 +340,7 @@ extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_ou
                "mg_smooth_fused: arrays must be 16-byte aligned with an even leading dimension");
     MG_REQUIRE(j0 >= 0 && j1 <= ny && j0 <= j1, "mg_smooth_fused: row range [%lld, %lld) outside the array", (long long)j0,
                (long long)j1);
-    MG_REQUIRE(x_in != x_out && r != x_out && (const double *)r != x_in, "mg_smooth_fused: aliased arrays");
+    MG_REQUIRE(x_in != x_out && r != x_out && (!r || (const double *)r != x_in), "mg_smooth_fused: aliased arrays");
     MG_REQUIRE(nx < ((i64)1 << 30) && ny < ((i64)1 << 30), "mg_smooth_fused: grid side too large");
     if (crs) {
         MG_REQUIRE(x_in, "mg_smooth_fused: prolongation needs x_in");
