@@ -116,7 +116,7 @@ int mg_prolong_add(const double *crs, int64_t cny, int64_t cnx, int64_t cld, dou
 
 /*
  * One fused smoothing pass (temporal blocking): in a single pass over memory
- *     [x_in += prolongation(crs)]  ->  `sweeps` (1..3) Jacobi sweeps  ->  [residual of the result]
+ *     [x_in += prolongation(crs)]  ->  `sweeps` (1..6) Jacobi sweeps  ->  [residual of the result]
  * with  x_in == NULL : start from x = 0 (the zeroed x of core/parallel_multigrid.py:276),
  *       crs  != NULL : bilinear prolongation of crs added first (mg_prolong_add with ofst_i = 0),
  *       r    != NULL : r = b - laplacian(x_out) on the interior cells of rows j0..j1-1 (+ max-norm

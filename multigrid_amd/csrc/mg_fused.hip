@@ -300,7 +300,7 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     a.ncb = (a.ntc + 3) / 4;
     int rpb = g_fused_rows;
     if (rpb <= 0) {
-        rpb = 256;
+        rpb = 128;
         while (rpb > 8 * D && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) < 2048) rpb >>= 1;
     }
     a.rpb = rpb;
@@ -314,7 +314,8 @@ static int launch_fused(FusedArgs a, hipStream_t st)
 template <int K, bool PROLONG, bool ZERO, bool RESID>
 static int pick_u(const FusedArgs &a, hipStream_t st)
 {
-    int u = g_fused_unroll;
+    // deep pipelines keep D three-row windows per column pair in registers: one pair per lane then
+    int u = (K + (RESID ? 1 : 0)) >= 5 ? 1 : g_fused_unroll;
     while (u > 1 && a.nx < 128 * u) u >>= 1;
     if (u == 2) return launch_fused<K, PROLONG, ZERO, RESID, 2>(a, st);
     return launch_fused<K, PROLONG, ZERO, RESID, 1>(a, st);
@@ -333,7 +334,7 @@ extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_ou
                                i64 fix_hi, i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, void *stream)
 {
     MG_REQUIRE(b && x_out, "mg_smooth_fused: null array");
-    MG_REQUIRE(sweeps >= 1 && sweeps <= 3, "mg_smooth_fused: 1..3 sweeps per pass, got %d", sweeps);
+    MG_REQUIRE(sweeps >= 1 && sweeps <= 6, "mg_smooth_fused: 1..6 sweeps per pass, got %d", sweeps);
     MG_REQUIRE(ny >= 3 && nx >= 3 && ld >= nx, "mg_smooth_fused: bad shape");
     MG_REQUIRE(ld % 2 == 0 && mg_aligned(b, 16) && mg_aligned(x_out, 16) && (!x_in || mg_aligned(x_in, 16)) &&
                    (!r || mg_aligned(r, 16)),
@@ -363,6 +364,9 @@ extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_ou
     switch (sweeps) {
     case 1: return pick_mode<1>(a, prolong, zero, resid, st);
     case 2: return pick_mode<2>(a, prolong, zero, resid, st);
-    default: return pick_mode<3>(a, prolong, zero, resid, st);
+    case 3: return pick_mode<3>(a, prolong, zero, resid, st);
+    case 4: return pick_mode<4>(a, prolong, zero, resid, st);
+    case 5: return pick_mode<5>(a, prolong, zero, resid, st);
+    default: return pick_mode<6>(a, prolong, zero, resid, st);
     }
 }

@@ -166,8 +166,8 @@ class SlabMultigrid:
         return src
 
     @staticmethod
-    def _chunks(n, most=3):
-        """n sweeps as passes of at most `most` sweeps, as even as possible (6 -> 3+3, 4 -> 2+2)."""
+    def _chunks(n, most=6):
+        """n sweeps as passes of at most `most` sweeps, as even as possible (8 -> 4+4)."""
         k = (n + most - 1) // most
         return [n // k + (1 if i < n % k else 0) for i in range(k)]
 

@@ -383,7 +383,7 @@ FUSED_SHAPES = [(9, 9), (40, 121), (70, 249), (66, 250), (300, 257), (130, 1000)
 
 
 @pytest.mark.parametrize("shape", FUSED_SHAPES, ids=str)
-@pytest.mark.parametrize("sweeps", [1, 2, 3])
+@pytest.mark.parametrize("sweeps", [1, 2, 3, 4, 6])
 @pytest.mark.parametrize("mode", ["plain", "zero", "prolong"])
 @pytest.mark.parametrize("resid", [False, True])
 @pytest.mark.parametrize("unroll", [1, 2])
