@@ -295,10 +295,9 @@ class SlabMultigrid:
             xa, xb = self._xa[l], self._xb[l]
             cnx = Ls[l + 1].nx
             if self.fused:
-                res = self._smooth_fused(l, xa, corr, cnx, self.N2, self.r[l] if self.keep_ascent_residuals else None)
-                if res is not xa:
-                    o.copy_(xa, res)
-                corr = xa
+                # the descent left x_l in xa; the result may land in either array, the next level up
+                # reads it from wherever it is and the next descent starts from zero anyway
+                corr = self._smooth_fused(l, xa, corr, cnx, self.N2, self.r[l] if self.keep_ascent_residuals else None)
                 continue
             o.prolong_add(corr, cnx, xa, L.nx, L.t0, L.t1, 0, -1)
             self._exchange(xa, L)
@@ -312,13 +311,16 @@ class SlabMultigrid:
     # ------------------------------------------------------------------ drivers
     def _run_cycle(self):
         if self.use_graph and self.world == 1:
+            # one graph per array the finest x starts the cycle in; a cycle may leave it in the other
             key = self._cur0
             if key not in self._graphs:
                 self.ops.graph_begin()
                 self._cycle()
-                self._graphs[key] = self.ops.graph_end()
-                assert self._cur0 == key  # the finest x returns to the same array every cycle
-            self.ops.graph_launch(self._graphs[key])
+                self._graphs[key] = (self.ops.graph_end(), self._cur0)
+                self._cur0 = key
+            g, end = self._graphs[key]
+            self.ops.graph_launch(g)
+            self._cur0 = end
         else:
             self._cycle()
 
@@ -373,7 +375,7 @@ class SlabMultigrid:
         return err
 
     def close(self):
-        for g in self._graphs.values():
+        for g, _ in self._graphs.values():
             self.ops.graph_destroy(g)
         self._graphs = {}
         if self._tail_graph is not None:
