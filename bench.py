@@ -65,7 +65,7 @@ def fill_rhs(eng, torch, n, rank):
     chunk = 256
     for t in range(a, e, chunk):
         t2 = min(t + chunk, e)
-        g = torch.arange(t, t2, device=dev, dtype=torch.float64) + (rank * P.levels[0].rows - 1)
+        g = torch.arange(t, t2, device=dev, dtype=torch.float64) + (rank * P.levels[0].rows - P.halo)
         Y = (-10.0 + h * torch.remainder(g, band)).unsqueeze(1)
         acc = torch.zeros((t2 - t, gnx), dtype=torch.float64, device=dev)
         sign = 1.0
@@ -76,10 +76,12 @@ def fill_rhs(eng, torch, n, rank):
     # Dirichlet boundary cells carry no equation
     eng.b0[:, 0] = 0
     eng.b0[:, gnx - 1] = 0
+    L0 = P.levels[0]
     if rank == 0:
-        eng.b0[1, :] = 0
+        eng.b0[L0.own0, :] = 0
     if rank == eng.world - 1:
-        eng.b0[P.levels[0].rows + 1, :] = 0
+        eng.b0[L0.own1 - 1, :] = 0
+    eng.set_b_rows(eng.local_rows(eng.b0))  # marks the halo of b as stale
     return h
 
 

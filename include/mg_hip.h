@@ -91,8 +91,9 @@ int mg_maxabs(const double *a, int64_t ny, int64_t nx, int64_t ld, uint64_t *nor
  * Full-weighting restriction, coarse rows J0 <= J < J1 (1 <= J0, J1 <= cny-1), coarse interior
  * columns; the fine centre of coarse (J,I) is (2J+ofst_j, 2I+ofst_i):
  *     crs[J,I] = f[c]/4 + (f[S]+f[N])*1/8 + ( (f[E]/8 + (f[SE]+f[NE])/16) + (f[W]/8 + (f[SW]+f[NW])/16) )
- * Replaces coarse, core/numba_modules.py:132-160.  ofst_i, ofst_j in {0,-1}
- * (core/parallel_multigrid.py:222-228).
+ * Replaces coarse, core/numba_modules.py:132-160.  The reference uses ofst_i, ofst_j in {0,-1}
+ * (core/parallel_multigrid.py:222-228); ofst_j may be any value <= 0 (row slabs with an H-row halo
+ * use -H).
  */
 int mg_restrict(const double *fine, int64_t fny, int64_t fnx, int64_t fld, double *crs, int64_t cny,
                 int64_t cnx, int64_t cld, int64_t J0, int64_t J1, int64_t ofst_i, int64_t ofst_j,

@@ -346,10 +346,11 @@ extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_ou
     if (crs) {
         MG_REQUIRE(x_in, "mg_smooth_fused: prolongation needs x_in");
         MG_REQUIRE(cny >= 2 && cnx >= 2 && cld >= cnx, "mg_smooth_fused: bad coarse shape");
-        MG_REQUIRE(ofst_j == 0 || ofst_j == -1, "mg_smooth_fused: ofst_j must be 0 or -1");
-        // every interior fine cell must have its coarse cells: 1 <= t - ofst_j <= 2*cny-3, 1 <= c <= 2*cnx-3
-        MG_REQUIRE(fix_lo + 1 - ofst_j >= 1 && fix_hi - 1 - ofst_j <= 2 * cny - 3 && nx - 2 <= 2 * cnx - 3,
-                   "mg_smooth_fused: coarse grid %lld x %lld does not cover the fine interior", (long long)cny,
+        MG_REQUIRE(ofst_j <= 0, "mg_smooth_fused: ofst_j must be <= 0");
+        // every fine cell of the produced rows must have its coarse cells: 1 <= t - ofst_j <= 2*cny-3,
+        // 1 <= c <= 2*cnx-3 (rows beyond, read only for the halo of the pipeline, are clamped)
+        MG_REQUIRE(j0 - ofst_j >= 1 && j1 - 1 - ofst_j <= 2 * cny - 3 && nx - 2 <= 2 * cnx - 3,
+                   "mg_smooth_fused: coarse grid %lld x %lld does not cover the fine rows", (long long)cny,
                    (long long)cnx);
     }
     if (j0 == j1) return 0;

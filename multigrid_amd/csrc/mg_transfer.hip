@@ -66,7 +66,7 @@ extern "C" int mg_restrict(const double *fine, i64 fny, i64 fnx, i64 fld, double
                            void *stream)
 {
     MG_REQUIRE(fine && crs, "mg_restrict: null array");
-    MG_REQUIRE((ofst_i == 0 || ofst_i == -1) && (ofst_j == 0 || ofst_j == -1), "mg_restrict: offsets must be 0 or -1");
+    MG_REQUIRE((ofst_i == 0 || ofst_i == -1) && ofst_j <= 0, "mg_restrict: ofst_i must be 0 or -1, ofst_j <= 0");
     MG_REQUIRE(cny >= 3 && cnx >= 3 && cld >= cnx && fld >= fnx, "mg_restrict: bad shapes");
     MG_REQUIRE(J0 >= 1 && J1 <= cny - 1 && J0 <= J1, "mg_restrict: coarse row range [%lld, %lld) outside 1..%lld",
                (long long)J0, (long long)J1, (long long)(cny - 1));
@@ -168,14 +168,17 @@ extern "C" int mg_prolong_add(const double *crs, i64 cny, i64 cnx, i64 cld, doub
                               i64 fbstride, void *stream)
 {
     MG_REQUIRE(crs && fine, "mg_prolong_add: null array");
-    MG_REQUIRE((ofst_i == 0 || ofst_i == -1) && (ofst_j == 0 || ofst_j == -1),
-               "mg_prolong_add: offsets must be 0 or -1");
+    MG_REQUIRE((ofst_i == 0 || ofst_i == -1) && ofst_j <= 0, "mg_prolong_add: ofst_i must be 0 or -1, ofst_j <= 0");
     MG_REQUIRE(cny >= 2 && cnx >= 2 && cld >= cnx && fld >= fnx && fny >= 1 && fnx >= 1, "mg_prolong_add: bad shapes");
     MG_REQUIRE(nbatch >= 1 && nbatch <= 65535, "mg_prolong_add: nbatch %lld outside 1..65535", (long long)nbatch);
     // the cells the reference touches: 1 <= t - ofst_j <= 2*cny-3 and 1 <= c - ofst_i <= 2*cnx-3
-    MG_REQUIRE(2 * cny - 3 + ofst_j <= fny - 1 && 2 * cnx - 3 + ofst_i <= fnx - 1,
+    // With the reference's offsets (0 / -1) every cell its four passes touch must exist; with a deeper
+    // row offset (slabs with several halo rows) the row range is simply clipped to the fine array.
+    MG_REQUIRE((ofst_j < -1 || 2 * cny - 3 + ofst_j <= fny - 1) && 2 * cnx - 3 + ofst_i <= fnx - 1,
                "mg_prolong_add: fine grid %lld x %lld too small for coarse %lld x %lld", (long long)fny, (long long)fnx,
                (long long)cny, (long long)cnx);
+    if (t0 < 0) t0 = 0;
+    if (t1 > fny) t1 = fny;
     if (t0 < 1 + ofst_j) t0 = 1 + ofst_j;
     if (t1 > 2 * cny - 3 + ofst_j + 1) t1 = 2 * cny - 3 + ofst_j + 1;
     if (c_lo < 1 + ofst_i) c_lo = 1 + ofst_i;

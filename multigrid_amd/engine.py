@@ -10,10 +10,14 @@ one Jacobi sweep + residual, then V-cycles of
 until max|r| <= epsilon, the divergence latch trips (:337-340) or 100 cycles have run (:270).
 
 What differs from the reference is where the data lives and how it is cut:
-* the four overlapping 2x2 blocks become P row slabs of the global grid (one per GPU/rank) with a
-  one-row halo on each side; a slab boundary is exchanged as ONE contiguous row per neighbour;
+* the four overlapping 2x2 blocks become P row slabs of the global grid (one per GPU/rank) with H
+  halo rows on each side; what crosses a slab boundary is a contiguous block of rows per neighbour;
 * restriction/prolongation need no per-rank offsets table: with slab boundaries on even rows the
-  fine centre of local coarse row T is local fine row 2T-1 on every rank (ofst_j = -1, ofst_i = 0);
+  fine centre of local coarse row T is local fine row 2T-H on every rank (ofst_j = -H, ofst_i = 0);
+* a level's smoothing (x = 0 or the prolongation, its 3 or 6 Jacobi sweeps, the residual) is ONE
+  fused pass over memory (mg_smooth_fused); with several ranks the halo is as deep as the pass
+  (H = 8), each rank recomputes the few rows next to its slab that the pass needs, and the halo
+  is exchanged once per pass instead of once per sweep;
 * the whole-domain levels live on rank 0 only: their right-hand side is gathered there, the tail
   runs as one hipGraph, and the correction is scattered back (the reference replicates the tail on
   every rank behind four broadcasts, :117-138);
@@ -36,7 +40,7 @@ class SlabMultigrid:
 
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
-                 max_cycles=100, use_graph=True, fused=True):
+                 max_cycles=100, use_graph=True, fused=True, halo=None):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -46,23 +50,24 @@ class SlabMultigrid:
             world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
             rank = dist.get_rank(group) if world > 1 else 0
         self.world, self.rank = world, rank
+        self.fused = fused and getattr(ops, "supports_fused", False)
+        if halo is None and world > 1 and not self.fused:
+            halo = 2  # one exchange per sweep needs one row; 2 keeps the halo even
+        self.plan = make_plan(gny, gnx, n_para, world, rank, h0, halo)
         self.comm = SlabComm(ops, group, world, rank)
-        self.plan = make_plan(gny, gnx, n_para, world, rank, h0)
         self.n_para = n_para
         self.epsilon = epsilon
         self.coarse_ordering = coarse_ordering
         self.fix_coarse_ascent = fix_coarse_ascent
         self.keep_ascent_residuals = keep_ascent_residuals
         self.max_cycles = max_cycles
-        # fused multi-sweep passes need halos as deep as the fused depth; until the slab exchange
-        # moves that many rows they are used on one rank only (results are identical either way)
-        self.fused = fused and world == 1 and getattr(ops, "supports_fused", False)
         self.use_graph = use_graph and getattr(ops, "supports_graphs", False)
         self.it = 0
         self.err_history = []
         self.diverged = False
 
         P = self.plan
+        H = P.halo
         z = ops.zeros
         # Jacobi levels: two x arrays (ping-pong), b, r.  b has one more level (the staging level).
         self._xa = [z(L.ny, L.ld) for L in P.levels[:n_para]]
@@ -71,21 +76,21 @@ class SlabMultigrid:
         self.r = [z(L.ny, L.ld) for L in P.levels[:n_para]]
         self._cur0 = 0  # which of (_xa[0], _xb[0]) holds the finest x
         self.norm = ops.norm_slots()
-        # whole-domain levels (rank 0).  Level 0 of them on one rank aliases the staging slab:
-        # local row t of the slab is global row t-1, so the grid is the slab minus its first row.
+        # Whole-domain levels (rank 0).  The first one is laid out like a slab that spans all ranks:
+        # local row t of it is global row t - H, so that every rank's window of the correction
+        # (its rows plus H halo rows each side) is a contiguous row range of one padded array.
         self.xw, self.bw, self.rw = [], [], []
-        S = P.levels[n_para]
+        S, W0 = P.levels[n_para], P.whole[0]
         if world == 1:
-            self._xw0_slab = z(S.ny, S.ld)
-            self.xw.append(self._xw0_slab[1:])
-            self.bw.append(self.b[n_para][1:])
-            self.rw.append(z(P.whole[0].ny, P.whole[0].ld))
+            self._xw0_pad = z(S.ny, S.ld)
+            self.xw.append(self._xw0_pad[H : H + W0.ny])
+            self.bw.append(self.b[n_para][H : H + W0.ny])
+            self.rw.append(z(W0.ny, W0.ld))
         elif rank == 0:
-            W = P.whole[0]
-            self._xw0_pad = z(W.ny + 1, W.ld)  # row 0 is a dummy so that slab windows start at p*R
-            self.xw.append(self._xw0_pad[1:])
-            self.bw.append(z(W.ny, W.ld))
-            self.rw.append(z(W.ny, W.ld))
+            self._xw0_pad = z(W0.ny + 2 * H, W0.ld)
+            self.xw.append(self._xw0_pad[H : H + W0.ny])
+            self.bw.append(z(W0.ny, W0.ld))
+            self.rw.append(z(W0.ny, W0.ld))
         if rank == 0:
             for W in P.whole[1:]:
                 self.xw.append(z(W.ny, W.ld))
@@ -96,6 +101,7 @@ class SlabMultigrid:
             self._scatter_buf = z(world * S.ny, S.ld) if rank == 0 else None
         self._graphs = {}
         self._tail_graph = None
+        self._b0_halo_valid = False
 
     # ------------------------------------------------------------------ data access
     @property
@@ -114,10 +120,11 @@ class SlabMultigrid:
     def owned_rows(self, level=0):
         """(first, last+1) local rows this rank owns, the global boundary rows included."""
         L = self.plan.levels[level]
-        return 1, L.rows + (2 if self.rank == self.world - 1 else 1)
+        return L.own0, L.own1
 
     def global_row_of_local(self, t, level=0):
-        return self.rank * self.plan.levels[level].rows - 1 + t
+        L = self.plan.levels[level]
+        return self.rank * L.rows - L.halo + t
 
     def set_x_rows(self, rows):
         """Set the owned rows of the finest x (both ping-pong arrays, so boundary values agree)."""
@@ -128,6 +135,7 @@ class SlabMultigrid:
     def set_b_rows(self, rows):
         a, e = self.owned_rows()
         self.b[0][a:e, : self.plan.gnx] = rows
+        self._b0_halo_valid = False
 
     def local_rows(self, arr):
         """The owned rows of a finest-level array as a (rows x gnx) view."""
@@ -135,83 +143,104 @@ class SlabMultigrid:
         return arr[a:e, : self.plan.gnx]
 
     # ------------------------------------------------------------------ halo exchange
-    def _exchange(self, arr, L, up=True, down=True):
-        """Fill the halo rows of `arr` from the neighbouring ranks: row 0 <- last owned row of the
-        rank above, row R+1 <- first owned row of the rank below.  `up`/`down` select which of my
-        halos are needed (the transfer operators need only one)."""
+    def _exchange(self, items, up=True, down=True):
+        """items: (array, its SlabLevel, depth) triples.  Fill `depth` halo rows of every array from
+        the neighbouring ranks, all in one batch: my upper halo <- the last owned rows of the rank
+        above, my lower halo <- the first owned rows of the rank below.  `up`/`down` select which of
+        my halos are filled.  Whole rows (padding included) are moved, so each message is one
+        contiguous block."""
         if self.world == 1:
             return
-        R, nx = L.rows, L.nx
         sends, recvs = [], []
-        if self.rank > 0:
-            if down:  # the rank above needs my first owned row as its lower halo
-                sends.append((arr[1, :nx], self.rank - 1))
-            if up:
-                recvs.append((arr[0, :nx], self.rank - 1))
-        if self.rank < self.world - 1:
-            if up:    # the rank below needs my last owned row as its upper halo
-                sends.append((arr[R, :nx], self.rank + 1))
-            if down:
-                recvs.append((arr[R + 1, :nx], self.rank + 1))
+        for arr, L, depth in items:
+            H, R = L.halo, L.rows
+            assert depth <= H and depth <= R
+            if self.rank > 0:
+                if down:  # the rank above needs my first owned rows as its lower halo
+                    sends.append((arr[H : H + depth].view(-1), self.rank - 1))
+                if up:
+                    recvs.append((arr[H - depth : H].view(-1), self.rank - 1))
+            if self.rank < self.world - 1:
+                if up:    # the rank below needs my last owned rows as its upper halo
+                    sends.append((arr[H + R - depth : H + R].view(-1), self.rank + 1))
+                if down:
+                    recvs.append((arr[H + R : H + R + depth].view(-1), self.rank + 1))
         self.comm.sendrecv(sends, recvs)
 
     # ------------------------------------------------------------------ building blocks
-    def _jacobi_sweeps(self, l, src, dst, n, finest=False):
-        """n x (sweep + exchange), ping-ponging src -> dst -> src ...; returns the array holding the result."""
-        L, o = self.plan.levels[l], self.ops
-        for _ in range(n):
-            o.jacobi(self.b[l], src, dst, L.nx, L.t0, L.t1, L.h, finest)
-            self._exchange(dst, L)
-            src, dst = dst, src
-        return src
-
     @staticmethod
     def _chunks(n, most=6):
         """n sweeps as passes of at most `most` sweeps, as even as possible (8 -> 4+4)."""
         k = (n + most - 1) // most
         return [n // k + (1 if i < n % k else 0) for i in range(k)]
 
-    def _smooth_fused(self, l, src, crs, cnx, n, r=None, norm=None):
-        """[src += P(crs)], n Jacobi sweeps, [residual into r (+ norm)] on level l as fused passes that
-        ping-pong between the level's two x arrays.  src None = start from zero.  Returns the array
-        that holds the result."""
+    def _smooth(self, l, src, crs, n, r=None, norm=None, finest=False, crs_has_halo=False):
+        """smooth_parallel (:100-114) on level l, optionally preceded by the prolongation of `crs`
+        (:309, :322): [src += P(crs)], n Jacobi sweeps, [residual into r (+ norm)].  src None = start
+        from x = 0 (:276).  The two x arrays of the level are used as ping-pong buffers; returns the
+        one that holds the result.  Halo rows of the result are NOT valid."""
         L, o = self.plan.levels[l], self.ops
         xa, xb = self._xa[l], self._xb[l]
-        chunks = self._chunks(n)
-        for ci, k in enumerate(chunks):
-            dst = xa if (src is None or src is xb) else xb
-            last = ci == len(chunks) - 1
-            if last and norm is not None:
-                o.norm_reset(norm)
-            o.smooth_fused(self.b[l], src, dst, r if last else None, crs if ci == 0 else None, L.nx, cnx, L.t0, L.t1,
-                           L.t0 - 1, L.t1, -1, k, L.h, norm if last else None)
+        cnx = self.plan.levels[l + 1].nx
+        if self.fused:
+            chunks = self._chunks(n, min(6, L.halo - (1 if r is not None else 0)) if self.world > 1 else 6)
+            for ci, k in enumerate(chunks):
+                dst = xa if (src is None or src is xb) else xb
+                first, last = ci == 0, ci == len(chunks) - 1
+                depth = k + (1 if (last and r is not None) else 0)
+                if src is not None:  # the pass reads `depth` rows beyond the rows it produces
+                    items = [(src, L, depth)]
+                    if first and crs is not None and not crs_has_halo:
+                        items.append((crs, self.plan.levels[l + 1], depth // 2 + 2))
+                    self._exchange(items)
+                if last and norm is not None:
+                    o.norm_reset(norm)
+                o.smooth_fused(self.b[l], src, dst, r if last else None, crs if first else None, L.nx, cnx, L.t0,
+                               L.t1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None)
+                src = dst
+            return src
+        # one kernel per operation, one single-row exchange per sweep
+        if src is None:
+            o.jacobi_from_zero(self.b[l], xa, L.nx, L.t0, L.t1, L.h, finest)
+            src, n = xa, n - 1
+        else:
+            if crs is not None:  # its lower halo row is valid: last exchanged after its last sweep
+                o.prolong_add(crs, cnx, src, L.nx, L.t0, L.t1, 0, L.oj)
+        self._exchange([(src, L, 1)])
+        for _ in range(n):
+            dst = xb if src is xa else xa
+            o.jacobi(self.b[l], src, dst, L.nx, L.t0, L.t1, L.h, finest)
+            self._exchange([(dst, L, 1)])
             src = dst
+        if r is not None:
+            if norm is not None:
+                o.norm_reset(norm)
+            o.residual(r, src, self.b[l], L.nx, L.t0, L.t1, L.h, norm, finest)
         return src
 
     def _smooth_level0(self, n, want_norm, crs=None):
-        """smooth_parallel on the finest level: exchange, n sweeps, residual (:100-114); with `crs`
-        the preceding prolongation (:322) is part of it."""
-        L, o = self.plan.levels[0], self.ops
         xs = [self._xa[0], self._xb[0]]
-        cur = xs[self._cur0]
-        if self.fused:
-            res = self._smooth_fused(0, cur, crs, self.plan.levels[1].nx, n, self.r[0], self.norm if want_norm else None)
-            self._cur0 = 0 if res is xs[0] else 1
-            return
-        if crs is not None:
-            o.prolong_add(crs, self.plan.levels[1].nx, cur, L.nx, L.t0, L.t1, 0, -1)
-        self._exchange(cur, L)
-        res = self._jacobi_sweeps(0, cur, xs[1 - self._cur0], n, finest=True)
+        if not self._b0_halo_valid:  # b0 only changes when the caller sets it
+            if self.fused:
+                self._exchange([(self.b[0], self.plan.levels[0], min(self.plan.halo, 6))])
+            self._b0_halo_valid = True
+        res = self._smooth(0, xs[self._cur0], crs, n, self.r[0], self.norm if want_norm else None, finest=True,
+                           crs_has_halo=self.n_para == 1)
         self._cur0 = 0 if res is xs[0] else 1
-        if want_norm:
-            o.norm_reset(self.norm)
-        o.residual(self.r[0], res, self.b[0], L.nx, L.t0, L.t1, L.h, self.norm if want_norm else None, finest=True)
+
+    def _restrict(self, l):
+        """r_l -> b_{l+1} (full weighting needs one halo row of r above), then the halo of b_{l+1}."""
+        o, Ls = self.ops, self.plan.levels
+        self._exchange([(self.r[l], Ls[l], 1)], up=True, down=False)
+        o.restrict(self.r[l], Ls[l].nx, self.b[l + 1], Ls[l + 1].nx, Ls[l + 1].t0, Ls[l + 1].t1, 0, Ls[l].oj)
+        if self.fused and l + 1 < self.n_para:
+            self._exchange([(self.b[l + 1], Ls[l + 1], min(self.plan.halo, 6))])
 
     def _tail(self):
         """Whole-domain levels on rank 0 (parallel_multigrid.py:291-304)."""
         o, W = self.ops, self.plan.whole
         nw = len(W)
-        o.zero_(self.xw[0] if self.world > 1 else self._xw0_slab)
+        o.zero_(self._xw0_pad)
         o.sor(self.bw[0], self.xw[0], self.rw[0], W[0].nx, W[0].h, self.N1, self.coarse_ordering)
         for i in range(1, nw):
             o.zero_(self.xw[i])
@@ -225,24 +254,25 @@ class SlabMultigrid:
 
     def _coarse_solve(self):
         """Gather the staging-level right-hand side to rank 0, run the tail, scatter the correction
-        into the staging slab (which then plays the role of the reference's split(x_wl[0]), :307)."""
+        (every rank's rows plus its halo rows) into the staging slab, which then plays the role of
+        the reference's split(x_wl[0]) (:307).  Returns the slab holding the correction."""
         o, P = self.ops, self.plan
-        S = P.levels[self.n_para]
+        S, H = P.levels[self.n_para], P.halo
         if self.world == 1:
             self._run_tail()
-            return self._xw0_slab
+            return self._xw0_pad
         stage = self.b[self.n_para]
+        R = S.rows
         if self.rank == 0:
             parts = list(self._gather_buf.view(self.world, S.ny, S.ld).unbind(0))
             self.comm.gather0(stage, parts)
-            R = S.rows
             with o.ctx():
                 g = self._gather_buf.view(self.world, S.ny, S.ld)
                 # owned rows of every rank, in order; the last global row is boundary (stays zero)
-                self.bw[0][: self.world * R].view(self.world, R, S.ld).copy_(g[:, 1 : R + 1, :])
+                self.bw[0][: self.world * R].view(self.world, R, S.ld).copy_(g[:, H : H + R, :])
             self._run_tail()
             with o.ctx():
-                # rank p gets global rows p*R-1 .. (p+1)*R of the correction = padded rows p*R .. p*R+R+1
+                # rank p gets global rows p*R-H .. (p+1)*R+H-1 = padded rows p*R .. p*R+R+2H-1
                 win = self._xw0_pad.as_strided((self.world, S.ny, S.ld), (R * S.ld, S.ld, 1))
                 self._scatter_buf.view(self.world, S.ny, S.ld).copy_(win)
             parts = list(self._scatter_buf.view(self.world, S.ny, S.ld).unbind(0))
@@ -264,48 +294,19 @@ class SlabMultigrid:
 
     def _cycle(self):
         """One V-cycle (the body of the loop at parallel_multigrid.py:270-347), norm included."""
-        o, P, n_para = self.ops, self.plan, self.n_para
-        Ls = P.levels
+        n_para = self.n_para
         # ---- descent
-        self._exchange(self.r[0], Ls[0], up=True, down=False)
-        o.restrict(self.r[0], Ls[0].nx, self.b[1], Ls[1].nx, Ls[1].t0, Ls[1].t1, 0, -1)
+        self._restrict(0)
         for l in range(1, n_para):
-            L = Ls[l]
-            xa, xb = self._xa[l], self._xb[l]
-            if self.fused:  # x = 0, N1 sweeps and the residual in one pass (result must land in xa)
-                res = self._smooth_fused(l, None, None, 0, self.N1, self.r[l])
-                if res is not xa:
-                    o.copy_(xa, res)
-                o.restrict(self.r[l], L.nx, self.b[l + 1], Ls[l + 1].nx, Ls[l + 1].t0, Ls[l + 1].t1, 0, -1)
-                continue
-            # x = 0 then N1 sweeps: the first sweep needs no x (all zeros), the rest ping-pong
-            o.jacobi_from_zero(self.b[l], xa, L.nx, L.t0, L.t1, L.h)
-            self._exchange(xa, L)
-            res = self._jacobi_sweeps(l, xa, xb, self.N1 - 1)
-            if res is not xa:  # only when N1 - 1 is odd: bring the result back into xa
-                o.copy_(xa, res)
-            o.residual(self.r[l], xa, self.b[l], L.nx, L.t0, L.t1, L.h)
-            self._exchange(self.r[l], L, up=True, down=False)
-            o.restrict(self.r[l], L.nx, self.b[l + 1], Ls[l + 1].nx, Ls[l + 1].t0, Ls[l + 1].t1, 0, -1)
+            self._smooth(l, None, None, self.N1, self.r[l])
+            self._restrict(l)
         # ---- coarse
         corr = self._coarse_solve()
         # ---- ascent
         for l in range(n_para - 1, 0, -1):
-            L = Ls[l]
-            xa, xb = self._xa[l], self._xb[l]
-            cnx = Ls[l + 1].nx
-            if self.fused:
-                # the descent left x_l in xa; the result may land in either array, the next level up
-                # reads it from wherever it is and the next descent starts from zero anyway
-                corr = self._smooth_fused(l, xa, corr, cnx, self.N2, self.r[l] if self.keep_ascent_residuals else None)
-                continue
-            o.prolong_add(corr, cnx, xa, L.nx, L.t0, L.t1, 0, -1)
-            self._exchange(xa, L)
-            res = self._jacobi_sweeps(l, xa, xb, self.N2)
-            assert res is xa
-            if self.keep_ascent_residuals:
-                o.residual(self.r[l], xa, self.b[l], L.nx, L.t0, L.t1, L.h)
-            corr = xa
+            # x_l of the descent is in _xa[l] (a from-zero pass always writes there)
+            corr = self._smooth(l, self._xa[l], corr, self.N2, self.r[l] if self.keep_ascent_residuals else None,
+                                crs_has_halo=l == n_para - 1)
         self._smooth_level0(self.N2, want_norm=True, crs=corr)
 
     # ------------------------------------------------------------------ drivers

@@ -44,18 +44,29 @@ def pitch(nx, align=16):
 
 @dataclass
 class SlabLevel:
-    """One Jacobi level on one rank.  Local row t holds global row rank*rows - 1 + t: row 0 is the
-    halo above (unused on rank 0), rows 1..rows are owned, row rows+1 is the halo below (on the last
-    rank: the global boundary row)."""
+    """One Jacobi level on one rank.  The local array has `halo` rows above and below the `rows` owned
+    ones: local row t holds global row rank*rows - halo + t.  On rank 0 the first owned row is the
+    global Dirichlet row (never updated; the rows above it are unused); the last rank additionally
+    holds the bottom Dirichlet row as local row halo + rows."""
     level: int
-    rows: int          # owned rows R_l (the last rank additionally holds the boundary row as t = R_l+1)
-    ny: int            # local rows = rows + 2
+    rows: int          # owned rows R_l
+    halo: int          # halo depth H (rows per side)
+    ny: int            # local rows = rows + 2 * halo
     nx: int            # global columns, boundary included
     ld: int
     h: float
-    t0: int            # first local row that is updated (global row 0 is boundary)
+    t0: int            # first local row that is updated
     t1: int            # one past the last updated local row
+    fix_lo: int        # local row of the top Dirichlet row (rows <= it never change), -1 if none
+    fix_hi: int        # local row of the bottom Dirichlet row, ny if none
+    own0: int          # first owned local row, Dirichlet rows included
+    own1: int          # one past the last owned local row
     gny: int           # global rows at this level
+
+    @property
+    def oj(self):
+        """Row offset of the transfer operators: local fine row of local coarse row T is 2T + oj."""
+        return -self.halo
 
 
 @dataclass
@@ -75,6 +86,7 @@ class SlabPlan:
     world: int
     rank: int
     h0: float
+    halo: int = 1
     levels: List[SlabLevel] = field(default_factory=list)  # 0 .. n_para (the last one is the staging level)
     whole: List[WholeLevel] = field(default_factory=list)
 
@@ -83,12 +95,15 @@ class SlabPlan:
         return (self.gny - 2) * (self.gnx - 2)
 
 
-def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0):
+def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0, halo=None):
     """Partition a (gny x gnx) grid (boundary included) for `n_para` Jacobi levels over `world` ranks.
 
     Requirements: gny-1 = world * R with R divisible by 2**n_para (so that coarse row g/2 lives on
     the rank that owns fine row g on every Jacobi level, and slab boundaries fall on even rows),
     gnx-1 divisible by 2**n_para, and at least 2 cells per side on the first whole-domain level.
+    `halo`: rows of halo per side; default 1 on one rank (nothing is exchanged), 8 on several (deep
+    enough for a fused pass of 6 sweeps + residual, and even, which keeps the fine/coarse row
+    correspondence t = 2T - halo on every level).
     """
     if n_para < 1:
         raise ValueError("n_para >= 1 required")
@@ -99,12 +114,23 @@ def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0):
         raise ValueError(f"rows per rank ({R0}) and columns-1 ({gnx - 1}) must be divisible by 2**n_para = {1 << n_para}")
     if ((gny - 1) >> n_para) < 2 or ((gnx - 1) >> n_para) < 2:
         raise ValueError("the first whole-domain level needs at least 2 cells per side")
-    plan = SlabPlan(gny, gnx, n_para, world, rank, h0)
+    H = (1 if world == 1 else 8) if halo is None else halo
+    if H != 1 and H % 2:
+        raise ValueError("halo must be 1 or even")
+    if world > 1 and (R0 >> (n_para - 1)) < H:
+        raise ValueError(f"the coarsest Jacobi level has {R0 >> (n_para - 1)} rows per rank, fewer than the halo depth {H}: "
+                         "use fewer Jacobi levels (n_para), fewer ranks or a smaller halo")
+    plan = SlabPlan(gny, gnx, n_para, world, rank, h0, H)
+    last = rank == world - 1
     for l in range(n_para + 1):
         R = R0 >> l
         nx = ((gnx - 1) >> l) + 1
-        plan.levels.append(SlabLevel(level=l, rows=R, ny=R + 2, nx=nx, ld=pitch(nx), h=h0 * 2 ** l,
-                                     t0=2 if rank == 0 else 1, t1=R + 1, gny=((gny - 1) >> l) + 1))
+        ny = R + 2 * H
+        plan.levels.append(SlabLevel(
+            level=l, rows=R, halo=H, ny=ny, nx=nx, ld=pitch(nx), h=h0 * 2 ** l,
+            t0=H + 1 if rank == 0 else H, t1=H + R,
+            fix_lo=H if rank == 0 else -1, fix_hi=H + R if last else ny,
+            own0=H, own1=H + R + (1 if last else 0), gny=((gny - 1) >> l) + 1))
     l = n_para
     while True:
         my, mx = (gny - 1) >> l, (gnx - 1) >> l
@@ -115,9 +141,11 @@ def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0):
     return plan
 
 
-def exchanges_per_cycle(n_para):
-    """Halo exchanges one V-cycle performs per rank (see engine.SlabMultigrid._cycle)."""
-    return 8 + 11 * (n_para - 1)
+def exchanges_per_cycle(n_para, fused=True):
+    """Halo exchange rounds one V-cycle performs per rank (see engine.SlabMultigrid._cycle): with
+    fused passes one round of r, one of b and one of (x, correction) per Jacobi level; with one
+    exchange per sweep 8 on the finest level and 11 on each of the others."""
+    return 3 * n_para if fused else 8 + 11 * (n_para - 1)
 
 
 def algorithmic_bytes_per_cycle(plan, keep_ascent_residuals=False, fused_zero_sweep=True):

@@ -67,16 +67,26 @@ class OracleOps:
             cur = norm.view(torch.float64)
             cur[0] = v if (np.isnan(v) or v > cur[0].item()) else cur[0].item()
 
+    # The oracle's transfer functions take the reference's row offsets 0 / -1.  A slab with an H-row
+    # halo uses offset -H: the same operator on row-shifted windows of the arrays.
     def restrict(self, f, fnx, c, cnx, J0, J1, oi, oj):
-        f0 = 2 * (J0 - 1)
+        o2 = 0 if oj % 2 == 0 else -1
+        f0 = 2 * (J0 - 1) + oj - o2  # first fine row of the window: its local offset becomes o2
         fs = np.ascontiguousarray(f.numpy()[f0 : 2 * (J1 - 1) + oj + 2, :fnx])
         cs = np.zeros((J1 - J0 + 2, cnx))
-        oracle.coarse(fs, cs, oi, oj)
+        oracle.coarse(fs, cs, oi, o2)
         c.numpy()[J0:J1, 1 : cnx - 1] = cs[1:-1, 1:-1]
 
     def prolong_add(self, c, cnx, f, fnx, t0, t1, oi, oj):
         fc = np.ascontiguousarray(f.numpy()[:, :fnx])
-        oracle.interpolate_add_to(np.ascontiguousarray(c.numpy()[:, :cnx]), fc, oi, oj)
+        if oj in (0, -1):
+            cc, o2 = np.ascontiguousarray(c.numpy()[:, :cnx]), oj
+        else:  # fine row t <-> coarse row (t - oj) / 2: drop the first -oj/2 coarse rows, offset 0
+            assert oj % 2 == 0
+            s = -oj // 2
+            n = min(c.shape[0] - s, (fc.shape[0] + 2) // 2)
+            cc, o2 = np.ascontiguousarray(c.numpy()[s : s + n, :cnx]), 0
+        oracle.interpolate_add_to(cc, fc, oi, o2)
         f.numpy()[t0:t1, 1 : fnx - 1] = fc[t0:t1, 1 : fnx - 1]
 
     supports_fused = True
@@ -84,12 +94,14 @@ class OracleOps:
     def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None):
         """The fused pass as the sequence it stands for: prolong_add, `sweeps` Jacobi sweeps, residual
         (rows between the fixed rows are the interior; only rows j0..j1-1 are written back)."""
-        cur = torch.zeros_like(x_out) if x_in is None else x_in.clone()
+        ny = x_out.shape[0]
+        lo, hi = max(fix_lo + 1, 1), min(fix_hi, ny - 1)  # rows a sweep may update; what lies beyond a
+        cur = torch.zeros_like(x_out) if x_in is None else x_in.clone()  # non-fixed end is halo
         if crs is not None:
-            self.prolong_add(crs, cnx, cur, nx, fix_lo + 1, fix_hi, 0, oj)
+            self.prolong_add(crs, cnx, cur, nx, max(fix_lo + 1, 0), min(fix_hi, ny), 0, oj)
         for _ in range(sweeps):
             nxt = cur.clone()
-            self.jacobi(b, cur, nxt, nx, fix_lo + 1, fix_hi, h)
+            self.jacobi(b, cur, nxt, nx, lo, hi, h)
             cur = nxt
         x_out[j0:j1] = cur[j0:j1]
         if r is not None:

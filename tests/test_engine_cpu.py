@@ -28,6 +28,7 @@ def _rhs(gny, gnx, seed=0):
 
 
 def _engine_run(gny, gnx, n_para, h, b, world, rank, cycles, group=None, **kw):
+    """b: global right-hand side; every rank takes its rows."""
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, ops=OracleOps(), world=world, rank=rank, group=group, **kw)
     R = eng.plan.levels[0].rows
     a, e = eng.owned_rows()
@@ -42,14 +43,14 @@ CASES = [(65, 65, 2), (129, 129, 3), (65, 129, 3), (257, 33, 2), (33, 33, 1)]
 
 
 @pytest.mark.parametrize("gny,gnx,n_para", CASES, ids=str)
-@pytest.mark.parametrize("ordering", ["lexicographic", "redblack"])
-def test_single_rank_equals_global_oracle(gny, gnx, n_para, ordering):
+@pytest.mark.parametrize("ordering,fused", [("lexicographic", True), ("lexicographic", False), ("redblack", True)])
+def test_single_rank_equals_global_oracle(gny, gnx, n_para, ordering, fused):
     b = _rhs(gny, gnx)
     h = 0.37
     ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0, ordering)
     ref.b[:] = b
     ref.solve(ncycles=4)
-    eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, 1, 0, 4, coarse_ordering=ordering)
+    eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, 1, 0, 4, coarse_ordering=ordering, fused=fused)
     assert errs == ref.err_hist.tolist()
     assert np.array_equal(x, ref.x)
     assert np.array_equal(r, ref.r)
@@ -70,7 +71,7 @@ def test_fix_coarse_ascent_and_ascent_residuals():
     assert errs == ref.err_hist.tolist()
     assert np.array_equal(x, ref.x)
     L1 = eng.plan.levels[1]
-    assert np.array_equal(eng.r[1].numpy()[1 : L1.rows + 2, : L1.nx], ref.array("r", 1))
+    assert np.array_equal(eng.r[1].numpy()[L1.own0 : L1.own1, : L1.nx], ref.array("r", 1))
     # the textbook ascent converges faster than the reference's loop bounds allow
     ref2 = oracle.GlobalSolver(gny, gnx, 2, 0.5, 0.0, "lexicographic")
     ref2.b[:] = b
@@ -109,14 +110,17 @@ def test_plan_and_layout():
     assert [L.rows for L in p.levels] == [4096 >> l for l in range(9)]
     assert p.levels[0].ld % 16 == 0 and p.levels[0].ld >= 32769
     assert (p.whole[0].ny, p.whole[0].nx) == (129, 129) and len(p.whole) == 7 and p.whole[-1].ny == 3
-    assert p.levels[0].t0 == 1 and make_plan(32769, 32769, 8, 8, 0).levels[0].t0 == 2
+    assert p.halo == 8 and p.levels[0].t0 == 8 and make_plan(32769, 32769, 8, 8, 0).levels[0].t0 == 9
+    assert make_plan(513, 513, 4).levels[0].t0 == 2 and make_plan(513, 513, 4).halo == 1
+    with pytest.raises(ValueError):
+        make_plan(129, 129, 5, world=4)  # 1 row per rank on the coarsest Jacobi level < halo
     with pytest.raises(ValueError):
         make_plan(65, 65, 2, world=3)
     with pytest.raises(ValueError):
         make_plan(65, 65, 6)
     with pytest.raises(ValueError):
         make_plan(67, 65, 2)
-    assert exchanges_per_cycle(4) == 8 + 33
+    assert exchanges_per_cycle(4, fused=False) == 8 + 33 and exchanges_per_cycle(4) == 12
 
 
 # ------------------------------------------------------------------ multi-rank, gloo
@@ -130,22 +134,23 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q):
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, world, rank, cycles)
+        eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, world, rank, cycles, fused=fused)
         q.put((rank, errs, x, r))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,gny,gnx,n_para", [(2, 65, 65, 2), (2, 129, 65, 3), (4, 129, 129, 3), (4, 257, 33, 2)],
-                         ids=str)
-def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para):
+@pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 65, 65, 2, True), (2, 129, 65, 3, True), (2, 129, 65, 3, False),
+                                                        (4, 129, 129, 3, True), (4, 257, 33, 2, True),
+                                                        (4, 257, 33, 2, False)], ids=str)
+def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused):
     b = _rhs(gny, gnx, 7)
     h = 0.37
     cycles = 3
@@ -155,7 +160,8 @@ def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused))
+             for rk in range(world)]
     for p in procs:
         p.start()
     out = {}

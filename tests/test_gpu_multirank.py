@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q):
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,7 +29,7 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from multigrid_amd.engine import SlabMultigrid
-        eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank)
+        eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank, fused=fused)
         assert eng.comm.staged
         R = eng.plan.levels[0].rows
         a, e = eng.owned_rows()
@@ -45,8 +45,9 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,gny,gnx,n_para", [(2, 257, 257, 3), (4, 1025, 513, 5)], ids=str)
-def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para):
+@pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 257, 257, 3, True), (4, 1025, 513, 5, True),
+                                                        (3, 769, 300 * 4 + 1, 2, True), (4, 1025, 513, 5, False)], ids=str)
+def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para, fused):
     import torch.multiprocessing as mp
     rng = np.random.default_rng(1)
     b = rng.standard_normal((gny, gnx))
@@ -59,7 +60,8 @@ def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused))
+             for rk in range(world)]
     for p in procs:
         p.start()
     out = {}
