@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--cpu-cycles", type=int, default=0, help="0 = choose for roughly 15 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="one kernel per operation instead of fused passes")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo stages messages through the host: lets several ranks share one GPU (rehearsal only)")
     return ap.parse_args()
 
 
@@ -125,9 +128,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
 
     from multigrid_amd.engine import SlabMultigrid
     from multigrid_amd.levels import algorithmic_bytes_per_cycle
@@ -137,7 +144,7 @@ def main():
     gny = world * 2 ** (n + 1) + 1
     h = 20.0 / 2 ** (n + 1)
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
-                        use_graph=not args.no_graph)
+                        use_graph=not args.no_graph, fused=not args.no_fused)
     fill_rhs(eng, torch, n, rank)
     torch.cuda.synchronize()
 
@@ -155,7 +162,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -197,7 +204,8 @@ def main():
                 "workload": f"{gny}x{gnx} fp64 Poisson V-cycle ({gnx}x{gnx} per GPU), test.py 8-vortex RHS",
                 "n": n, "n_para": n_para, "grid": [gny, gnx], "unknowns": unknowns,
                 "coarse_ordering": args.ordering, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
-                "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph),
+                "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph), "fused_passes": bool(eng.fused),
+                "halo_rows": eng.plan.halo, "backend": args.backend if world > 1 else None,
             },
             "roofline": {
                 "kernel": "mg_stencil5_kernel<0 (Jacobi), 2, 2, true (finest level)>",
