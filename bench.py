@@ -38,11 +38,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=14, help="grid is (2**(n+1)+1) columns wide; 14 -> 32769")
-    ap.add_argument("--n-para", type=int, default=8, help="number of Jacobi (slab-distributed) levels")
+    ap.add_argument("--exp", dest="n", type=int, default=14, help="grid is (2**(n+1)+1) columns wide; 14 -> 32769")
+    ap.add_argument("--jacobi-levels", dest="n_para", type=int, default=8, help="number of Jacobi (slab-distributed) levels")
     ap.add_argument("--ordering", default="lexicographic", choices=["lexicographic", "redblack"])
     ap.add_argument("--roofline-iters", type=int, default=20)
-    ap.add_argument("--cpu-n", type=int, default=12, help="grid exponent of the CPU baseline sample")
+    ap.add_argument("--cpu-exp", dest="cpu_n", type=int, default=12, help="grid exponent of the CPU baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=0, help="0 = choose for roughly 15 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
