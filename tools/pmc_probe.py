@@ -31,6 +31,7 @@ def main():
     y = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
     b = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
     c = torch.rand((L1.ny, L1.ld), dtype=torch.float64, device="cuda")
+    r = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
     slots = ops.norm_slots()
     torch.cuda.synchronize()
     ops.begin()
@@ -40,6 +41,9 @@ def main():
         ops.restrict(x, L0.nx, c, L1.nx, L1.t0, L1.t1, 0, -1)
         ops.prolong_add(c, L1.nx, x, L0.nx, L0.t0, L0.t1, 0, -1)
         ops.jacobi_from_zero(b, y, L0.nx, L0.t0, L0.t1, 0.5, True)
+        ops.smooth_fused(b, x, y, r, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, 0.5, slots)
+        ops.smooth_fused(b, None, y, r, None, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 3, 0.5, None)
+        ops.smooth_fused(b, x, y, None, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, 0.5, None)
         ops.synchronize()
         print(f"rep {k} done", flush=True)
     pts = (L0.t1 - L0.t0) * (L0.nx - 2)
