@@ -40,7 +40,7 @@ class SlabMultigrid:
 
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
-                 max_cycles=100, use_graph=True, fused=True, halo=None):
+                 max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -61,6 +61,10 @@ class SlabMultigrid:
         self.fix_coarse_ascent = fix_coarse_ascent
         self.keep_ascent_residuals = keep_ascent_residuals
         self.max_cycles = max_cycles
+        # With the reference's loop bounds nothing computed on the whole-domain levels below the first
+        # ever reaches the solution (:302).  They are a pure function of rw[0], so unless asked to they
+        # are not computed every cycle but on demand (sync_whole_levels), with identical values.
+        self.eager_dead_levels = eager_dead_levels or fix_coarse_ascent
         self.use_graph = use_graph and getattr(ops, "supports_graphs", False)
         self.it = 0
         self.err_history = []
@@ -242,6 +246,13 @@ class SlabMultigrid:
         nw = len(W)
         o.zero_(self._xw0_pad)
         o.sor(self.bw[0], self.xw[0], self.rw[0], W[0].nx, W[0].h, self.N1, self.coarse_ordering)
+        if self.eager_dead_levels:
+            self._tail_below()
+
+    def _tail_below(self):
+        """The whole-domain levels below the first (parallel_multigrid.py:294-304)."""
+        o, W = self.ops, self.plan.whole
+        nw = len(W)
         for i in range(1, nw):
             o.zero_(self.xw[i])
             o.restrict(self.rw[i - 1], W[i - 1].nx, self.bw[i], W[i].nx, 1, W[i].ny - 1, 0, 0)
@@ -251,6 +262,15 @@ class SlabMultigrid:
             c, f = nw - i + 1, nw - i
             o.prolong_add(self.xw[c], W[c].nx, self.xw[f], W[f].nx, 0, W[f].ny, 0, 0)
             o.sor(self.bw[f], self.xw[f], self.rw[f], W[f].nx, W[f].h, self.N2, self.coarse_ordering)
+
+    def sync_whole_levels(self):
+        """Bring xw[1:], bw[1:], rw[1:] to the state the reference's arrays have after the last cycle
+        (no-op when they are computed every cycle).  Rank 0 holds these levels."""
+        if not self.eager_dead_levels and self.rank == 0 and self.xw:
+            self.ops.begin()
+            self._tail_below()
+            self.ops.end()
+            self.ops.synchronize()
 
     def _coarse_solve(self):
         """Gather the staging-level right-hand side to rank 0, run the tail, scatter the correction

@@ -62,6 +62,7 @@ def test_engine_equals_global_oracle(gny, gnx, n_para, ordering, graph):
     assert errs == ref.err_hist.tolist()
     assert np.array_equal(_rows(eng, eng.x0), ref.x)
     assert np.array_equal(_rows(eng, eng.r0), ref.r)
+    eng.sync_whole_levels()
     for k, W in enumerate(eng.plan.whole):
         assert np.array_equal(eng.xw[k].cpu().numpy()[:, : W.nx], ref.array("xw", k))
     eng.close()
