@@ -134,6 +134,20 @@ int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *
                     int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld, int64_t j0,
                     int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps, double h,
                     uint64_t *norm_slots, void *stream);
+/*
+ * mg_smooth_fused with the full-weighting restriction of the residual fused in as a last stage:
+ * coarse rows T0 <= T < T1 of coarse_b (cbny x cbnx, interior columns) are written as mg_restrict
+ * (ofst_i = 0, the same ofst_j) would compute them from the residual; each coarse row's fine centre
+ * row 2T + ofst_j must be one of the produced rows j0..j1-1.  r may be NULL: the residual is then
+ * not stored at all (its Dirichlet cells count as 0, which is what a never-written r array holds).
+ * Replaces the residual + exchange + coarse sequence of core/parallel_multigrid.py:114,:272-273,
+ * :287-288.  Reads rows j0-D .. j1+D-1 with D = sweeps + 2.
+ */
+int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
+                             int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld,
+                             int64_t j0, int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps,
+                             double h, uint64_t *norm_slots, double *coarse_b, int64_t cbny, int64_t cbnx,
+                             int64_t cbld, int64_t T0, int64_t T1, void *stream);
 /* Tuning knobs of mg_smooth_fused: column pairs per lane (1 or 2), rows per tile (0 = automatic). */
 int mg_set_fused_tuning(int unroll, int rows);
 

@@ -35,6 +35,8 @@ struct FusedArgs {
     int rpb, ncb, nrc, ntc, oj;
     double h2, hh;
     u64 *norm;
+    double *cb;          // coarse right-hand side produced by the fused restriction (RESTRICT)
+    i64 cbnx, cbld, T0, T1; // its columns, leading dimension, and the coarse rows to produce
 };
 
 __device__ __forceinline__ double lane_bcast(double v, int src)
@@ -43,11 +45,13 @@ __device__ __forceinline__ double lane_bcast(double v, int src)
                             __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-template <int K, bool PROLONG, bool ZERO, bool RESID, int U>
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
 __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
 {
-    constexpr int D = K + (RESID ? 1 : 0);
-    constexpr int Dv = (D + 1) & ~1;
+    static_assert(!RESTRICT || RESID, "the restriction consumes the residual stage");
+    constexpr int D = K + (RESID ? 1 : 0);   // pipeline stages that hold a three-row window
+    constexpr int DC = D + (RESTRICT ? 1 : 0); // dependency depth: what validity shrinks by
+    constexpr int Dv = (DC + 1) & ~1;
     constexpr int W = 128 * U;
     constexpr int STRIDE = W - 2 * Dv;
     int cb, rc;
@@ -122,7 +126,12 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
             }
         };
 
-        const i64 i0 = rb - D, i1 = re + D; // input rows streamed: i0 .. i1-1 (clamped into the array)
+        const i64 i0 = rb - DC, i1 = re + DC; // input rows streamed: i0 .. i1-1 (clamped into the array)
+        double rw[RESTRICT ? 3 : 1][U][2];    // residual rows i-K-3 .. i-K-1 (oldest first)
+#pragma unroll
+        for (int q = 0; q < (RESTRICT ? 3 : 1); ++q)
+#pragma unroll
+            for (int g = 0; g < U; ++g) rw[q][g][0] = rw[q][g][1] = 0.0;
         double xn[U][2], bn[U][2];          // prefetched: x row i, b row i-1
         if constexpr (!ZERO) load_pairs(a.xin, i0, xn);
         load_pairs(a.b, i0 - 1, bn);
@@ -225,38 +234,82 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
             // ---- residual of row i-K-1 from the stage-K window
             if constexpr (RESID) {
                 const i64 row = i - K - 1;
-                if (row >= rb && row < re && row > a.flo && row < a.fhi) {
-                    double *rrow = a.r + row * ld;
+                const bool mine = row >= rb && row < re;
+                const bool need = RESTRICT ? (row >= rb - 1 && row <= re) : mine; // uniform
+                if (need) {
+                    const bool rint = row > a.flo && row < a.fhi; // uniform
+                    double rv[U][2];
+                    if (rint) {
 #pragma unroll
-                    for (int g = 0; g < U; ++g) {
-                        double west = wave_from_prev(w[K][1][g][1]);
-                        double east = wave_from_next(w[K][1][g][0]);
-                        if (g > 0) {
-                            const double t = lane_bcast(w[K][1][g > 0 ? g - 1 : 0][1], 63);
-                            west = lane == 0 ? t : west;
-                        }
-                        if (g + 1 < U) {
-                            const double t = lane_bcast(w[K][1][g + 1 < U ? g + 1 : 0][0], 0);
-                            east = isR ? t : east;
-                        }
-                        const double c0v = w[K][1][g][0], c1v = w[K][1][g][1];
-                        double r0 = br[K][g][0] - west * a.hh - (c1v + w[K][0][g][0] + w[K][2][g][0]) * a.hh + (c0v * a.hh) * 4;
-                        double r1 = br[K][g][1] - c0v * a.hh - (east + w[K][0][g][1] + w[K][2][g][1]) * a.hh + (c1v * a.hh) * 4;
-                        if (st[g]) {
-                            // cells outside the interior keep what r holds (the reference never writes them)
-                            if (!(ic[g][0] && ic[g][1])) {
-                                double2 keep = *reinterpret_cast<double2 *>(rrow + c0[g]);
-                                if (!ic[g][0]) r0 = keep.x;
-                                if (!ic[g][1]) r1 = keep.y;
+                        for (int g = 0; g < U; ++g) {
+                            double west = wave_from_prev(w[K][1][g][1]);
+                            double east = wave_from_next(w[K][1][g][0]);
+                            if (g > 0) {
+                                const double t = lane_bcast(w[K][1][g > 0 ? g - 1 : 0][1], 63);
+                                west = lane == 0 ? t : west;
                             }
-                            *reinterpret_cast<double2 *>(rrow + c0[g]) = make_double2(r0, r1);
-                            if (ic[g][0]) {
-                                u64 key = (u64)__double_as_longlong(fabs(r0));
-                                nmax = key > nmax ? key : nmax;
+                            if (g + 1 < U) {
+                                const double t = lane_bcast(w[K][1][g + 1 < U ? g + 1 : 0][0], 0);
+                                east = isR ? t : east;
                             }
-                            if (ic[g][1]) {
-                                u64 key = (u64)__double_as_longlong(fabs(r1));
-                                nmax = key > nmax ? key : nmax;
+                            const double c0v = w[K][1][g][0], c1v = w[K][1][g][1];
+                            rv[g][0] = br[K][g][0] - west * a.hh - (c1v + w[K][0][g][0] + w[K][2][g][0]) * a.hh + (c0v * a.hh) * 4;
+                            rv[g][1] = br[K][g][1] - c0v * a.hh - (east + w[K][0][g][1] + w[K][2][g][1]) * a.hh + (c1v * a.hh) * 4;
+                            // cells outside the interior keep what r holds (the reference never writes
+                            // them); without an r array they are the zeros such an array would hold
+                            if (!(ic[g][0] && ic[g][1]) && (st[g] || RESTRICT)) {
+                                double2 keep = make_double2(0.0, 0.0);
+                                if (a.r) keep = *reinterpret_cast<const double2 *>(a.r + row * ld + cl[g]);
+                                if (!ic[g][0]) rv[g][0] = keep.x;
+                                if (!ic[g][1]) rv[g][1] = keep.y;
+                            }
+                        }
+                        if (mine) {
+#pragma unroll
+                            for (int g = 0; g < U; ++g)
+                                if (st[g]) {
+                                    if (a.r) *reinterpret_cast<double2 *>(a.r + row * ld + c0[g]) = make_double2(rv[g][0], rv[g][1]);
+                                    if (ic[g][0]) {
+                                        u64 key = (u64)__double_as_longlong(fabs(rv[g][0]));
+                                        nmax = key > nmax ? key : nmax;
+                                    }
+                                    if (ic[g][1]) {
+                                        u64 key = (u64)__double_as_longlong(fabs(rv[g][1]));
+                                        nmax = key > nmax ? key : nmax;
+                                    }
+                                }
+                        }
+                    } else if constexpr (RESTRICT) { // a Dirichlet row: r as stored
+#pragma unroll
+                        for (int g = 0; g < U; ++g) rv[g][0] = rv[g][1] = 0.0;
+                        if (a.r && row >= 0 && row <= a.ny - 1) load_pairs(a.r, row, rv);
+                    }
+                    if constexpr (RESTRICT) {
+#pragma unroll
+                        for (int g = 0; g < U; ++g)
+#pragma unroll
+                            for (int v = 0; v < 2; ++v)
+                                rw[0][g][v] = rw[1][g][v], rw[1][g][v] = rw[2][g][v], rw[2][g][v] = rv[g][v];
+                        // full weighting of coarse row T, whose fine centre row is row-1 (owned by this tile)
+                        const i64 ctr = row - 1;
+                        if (ctr >= rb && ctr < re && ((ctr - a.oj) & 1) == 0) {
+                            const i64 T = (ctr - a.oj) >> 1;
+                            if (T >= a.T0 && T < a.T1) {
+#pragma unroll
+                                for (int g = 0; g < U; ++g) {
+                                    const double a_right = rw[1][g][1] / 8 + (rw[2][g][1] + rw[0][g][1]) / 16;
+                                    double a_left = wave_from_prev(a_right);
+                                    if (g > 0) {
+                                        const double pr = rw[1][g > 0 ? g - 1 : 0][1] / 8 +
+                                                          (rw[2][g > 0 ? g - 1 : 0][1] + rw[0][g > 0 ? g - 1 : 0][1]) / 16;
+                                        const double t = lane_bcast(pr, 63);
+                                        a_left = lane == 0 ? t : a_left;
+                                    }
+                                    double v = rw[1][g][0] / 4 + (rw[2][g][0] + rw[0][g][0]) * 1 / 8;
+                                    v += a_right + a_left;
+                                    const i64 I = c0[g] >> 1;
+                                    if (st[g] && I >= 1 && I <= a.cbnx - 2) a.cb[T * a.cbld + I] = v;
+                                }
                             }
                         }
                     }
@@ -292,10 +345,10 @@ extern "C" int mg_set_fused_tuning(int unroll, int rows)
     return 0;
 }
 
-template <int K, bool PROLONG, bool ZERO, bool RESID, int U>
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
 static int launch_fused(FusedArgs a, hipStream_t st)
 {
-    constexpr int D = K + (RESID ? 1 : 0), Dv = (D + 1) & ~1, W = 128 * U, STRIDE = W - 2 * Dv;
+    constexpr int D = K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0), Dv = (D + 1) & ~1, W = 128 * U, STRIDE = W - 2 * Dv;
     a.ntc = a.nx <= W ? 1 : (int)((a.nx - W + STRIDE - 1) / STRIDE) + 1;
     a.ncb = (a.ntc + 3) / 4;
     int rpb = g_fused_rows;
@@ -305,33 +358,39 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     }
     a.rpb = rpb;
     a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
-    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, U>), dim3((unsigned)(a.ncb * a.nrc)), dim3(256), 0, st,
-                       a);
+    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U>), dim3((unsigned)(a.ncb * a.nrc)),
+                       dim3(256), 0, st, a);
     MG_LAUNCH_CHECK("mg_smooth_fused");
     return 0;
 }
 
-template <int K, bool PROLONG, bool ZERO, bool RESID>
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT>
 static int pick_u(const FusedArgs &a, hipStream_t st)
 {
     // deep pipelines keep D three-row windows per column pair in registers: one pair per lane then
-    int u = (K + (RESID ? 1 : 0)) >= 5 ? 1 : g_fused_unroll;
+    int u = (K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0)) >= 5 ? 1 : g_fused_unroll;
     while (u > 1 && a.nx < 128 * u) u >>= 1;
-    if (u == 2) return launch_fused<K, PROLONG, ZERO, RESID, 2>(a, st);
-    return launch_fused<K, PROLONG, ZERO, RESID, 1>(a, st);
+    if (u == 2) return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 2>(a, st);
+    return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 1>(a, st);
 }
 
 template <int K>
-static int pick_mode(const FusedArgs &a, bool prolong, bool zero, bool resid, hipStream_t st)
+static int pick_mode(const FusedArgs &a, bool prolong, bool zero, bool resid, bool restr, hipStream_t st)
 {
-    if (zero) return resid ? pick_u<K, false, true, true>(a, st) : pick_u<K, false, true, false>(a, st);
-    if (prolong) return resid ? pick_u<K, true, false, true>(a, st) : pick_u<K, true, false, false>(a, st);
-    return resid ? pick_u<K, false, false, true>(a, st) : pick_u<K, false, false, false>(a, st);
+    if (restr) {
+        if (zero) return pick_u<K, false, true, true, true>(a, st);
+        if (prolong) return pick_u<K, true, false, true, true>(a, st);
+        return pick_u<K, false, false, true, true>(a, st);
+    }
+    if (zero) return resid ? pick_u<K, false, true, true, false>(a, st) : pick_u<K, false, true, false, false>(a, st);
+    if (prolong) return resid ? pick_u<K, true, false, true, false>(a, st) : pick_u<K, true, false, false, false>(a, st);
+    return resid ? pick_u<K, false, false, true, false>(a, st) : pick_u<K, false, false, false, false>(a, st);
 }
 
-extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
-                               i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo,
-                               i64 fix_hi, i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, void *stream)
+static int smooth_fused_impl(const double *b, const double *x_in, double *x_out, double *r, const double *crs, i64 ny,
+                             i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo, i64 fix_hi,
+                             i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, bool want_resid, double *coarse_b,
+                             i64 cbny, i64 cbnx, i64 cbld, i64 T0, i64 T1, void *stream)
 {
     MG_REQUIRE(b && x_out, "mg_smooth_fused: null array");
     MG_REQUIRE(sweeps >= 1 && sweeps <= 6, "mg_smooth_fused: 1..6 sweeps per pass, got %d", sweeps);
@@ -353,6 +412,18 @@ extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_ou
                    "mg_smooth_fused: coarse grid %lld x %lld does not cover the fine rows", (long long)cny,
                    (long long)cnx);
     }
+    if (coarse_b) {
+        MG_REQUIRE(ofst_j <= 0 && cbny >= 3 && cbnx >= 3 && cbld >= cbnx, "mg_smooth_fused_restrict: bad coarse shape");
+        MG_REQUIRE(T0 >= 1 && T1 <= cbny - 1 && T0 <= T1, "mg_smooth_fused_restrict: coarse rows [%lld, %lld) outside 1..%lld",
+                   (long long)T0, (long long)T1, (long long)(cbny - 1));
+        MG_REQUIRE(2 * (cbnx - 2) + 1 <= nx - 1, "mg_smooth_fused_restrict: fine grid too narrow for %lld coarse columns",
+                   (long long)cbnx);
+        // every coarse row's fine centre row must be one of the rows this pass produces
+        MG_REQUIRE(T0 == T1 || (2 * T0 + ofst_j >= j0 && 2 * (T1 - 1) + ofst_j < j1 && 2 * T0 + ofst_j - 1 >= 0 &&
+                                2 * (T1 - 1) + ofst_j + 1 <= ny - 1),
+                   "mg_smooth_fused_restrict: coarse rows [%lld, %lld) are not centred on the produced fine rows",
+                   (long long)T0, (long long)T1);
+    }
     if (j0 == j1) return 0;
     FusedArgs a;
     a.b = b, a.xin = x_in, a.xout = x_out, a.r = r, a.crs = crs;
@@ -360,14 +431,35 @@ extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_ou
     a.j0 = j0, a.j1 = j1, a.flo = fix_lo, a.fhi = fix_hi, a.oj = (int)ofst_j;
     a.h2 = h * h, a.hh = 1 / (h * h), a.norm = (u64 *)norm_slots;
     a.rpb = a.ncb = a.nrc = a.ntc = 0;
-    const bool zero = x_in == nullptr, prolong = crs != nullptr, resid = r != nullptr;
+    a.cb = coarse_b, a.cbnx = cbnx, a.cbld = cbld, a.T0 = T0, a.T1 = T1;
+    const bool zero = x_in == nullptr, prolong = crs != nullptr, restr = coarse_b != nullptr;
+    const bool resid = want_resid || restr;
     hipStream_t st = (hipStream_t)stream;
     switch (sweeps) {
-    case 1: return pick_mode<1>(a, prolong, zero, resid, st);
-    case 2: return pick_mode<2>(a, prolong, zero, resid, st);
-    case 3: return pick_mode<3>(a, prolong, zero, resid, st);
-    case 4: return pick_mode<4>(a, prolong, zero, resid, st);
-    case 5: return pick_mode<5>(a, prolong, zero, resid, st);
-    default: return pick_mode<6>(a, prolong, zero, resid, st);
+    case 1: return pick_mode<1>(a, prolong, zero, resid, restr, st);
+    case 2: return pick_mode<2>(a, prolong, zero, resid, restr, st);
+    case 3: return pick_mode<3>(a, prolong, zero, resid, restr, st);
+    case 4: return pick_mode<4>(a, prolong, zero, resid, restr, st);
+    case 5: return pick_mode<5>(a, prolong, zero, resid, restr, st);
+    default: return pick_mode<6>(a, prolong, zero, resid, restr, st);
     }
+}
+
+extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
+                               i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo,
+                               i64 fix_hi, i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, void *stream)
+{
+    return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
+                             h, norm_slots, r != nullptr, nullptr, 0, 0, 0, 0, 0, stream);
+}
+
+extern "C" int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out, double *r,
+                                        const double *crs, i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0,
+                                        i64 j1, i64 fix_lo, i64 fix_hi, i64 ofst_j, int sweeps, double h,
+                                        uint64_t *norm_slots, double *coarse_b, i64 cbny, i64 cbnx, i64 cbld, i64 T0,
+                                        i64 T1, void *stream)
+{
+    MG_REQUIRE(coarse_b, "mg_smooth_fused_restrict: null coarse array");
+    return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
+                             h, norm_slots, true, coarse_b, cbny, cbnx, cbld, T0, T1, stream);
 }

@@ -178,20 +178,24 @@ class SlabMultigrid:
         k = (n + most - 1) // most
         return [n // k + (1 if i < n % k else 0) for i in range(k)]
 
-    def _smooth(self, l, src, crs, n, r=None, norm=None, finest=False, crs_has_halo=False):
+    def _smooth(self, l, src, crs, n, r=None, norm=None, finest=False, crs_has_halo=False, restrict=False):
         """smooth_parallel (:100-114) on level l, optionally preceded by the prolongation of `crs`
         (:309, :322): [src += P(crs)], n Jacobi sweeps, [residual into r (+ norm)].  src None = start
         from x = 0 (:276).  The two x arrays of the level are used as ping-pong buffers; returns the
-        one that holds the result.  Halo rows of the result are NOT valid."""
+        one that holds the result.  Halo rows of the result are NOT valid.  restrict=True also
+        produces b_{l+1} from the residual (:273, :288), fused into the pass when passes are fused (the
+        residual is then stored only if `r` is given)."""
         L, o = self.plan.levels[l], self.ops
         xa, xb = self._xa[l], self._xb[l]
         cnx = self.plan.levels[l + 1].nx
         if self.fused:
-            chunks = self._chunks(n, min(6, L.halo - (1 if r is not None else 0)) if self.world > 1 else 6)
+            extra = (2 if restrict else 1 if r is not None else 0)
+            chunks = self._chunks(n, min(6, L.halo - extra) if self.world > 1 else 6)
+            Lc = self.plan.levels[l + 1]
             for ci, k in enumerate(chunks):
                 dst = xa if (src is None or src is xb) else xb
                 first, last = ci == 0, ci == len(chunks) - 1
-                depth = k + (1 if (last and r is not None) else 0)
+                depth = k + (extra if last else 0)
                 if src is not None:  # the pass reads `depth` rows beyond the rows it produces
                     items = [(src, L, depth)]
                     if first and crs is not None and not crs_has_halo:
@@ -199,9 +203,15 @@ class SlabMultigrid:
                     self._exchange(items)
                 if last and norm is not None:
                     o.norm_reset(norm)
-                o.smooth_fused(self.b[l], src, dst, r if last else None, crs if first else None, L.nx, cnx, L.t0,
-                               L.t1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None)
+                if last and restrict:
+                    o.smooth_fused(self.b[l], src, dst, r, crs if first else None, L.nx, cnx, L.t0, L.t1, L.fix_lo,
+                                   L.fix_hi, L.oj, k, L.h, norm, self.b[l + 1], Lc.nx, Lc.t0, Lc.t1)
+                else:
+                    o.smooth_fused(self.b[l], src, dst, r if last else None, crs if first else None, L.nx, cnx, L.t0,
+                                   L.t1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None)
                 src = dst
+            if restrict and l + 1 < self.n_para:
+                self._exchange([(self.b[l + 1], Lc, self.plan.halo - 1)])
             return src
         # one kernel per operation, one single-row exchange per sweep
         if src is None:
@@ -220,16 +230,19 @@ class SlabMultigrid:
             if norm is not None:
                 o.norm_reset(norm)
             o.residual(r, src, self.b[l], L.nx, L.t0, L.t1, L.h, norm, finest)
+        if restrict:
+            self._restrict(l)
         return src
 
     def _smooth_level0(self, n, want_norm, crs=None):
         xs = [self._xa[0], self._xb[0]]
         if not self._b0_halo_valid:  # b0 only changes when the caller sets it
-            if self.fused:
-                self._exchange([(self.b[0], self.plan.levels[0], min(self.plan.halo, 6))])
+            if self.fused and self.world > 1:
+                self._exchange([(self.b[0], self.plan.levels[0], self.plan.halo - 1)])
             self._b0_halo_valid = True
+        # the residual of the finest level is restricted right away: b_1 is ready for the next descent
         res = self._smooth(0, xs[self._cur0], crs, n, self.r[0], self.norm if want_norm else None, finest=True,
-                           crs_has_halo=self.n_para == 1)
+                           crs_has_halo=self.n_para == 1, restrict=True)
         self._cur0 = 0 if res is xs[0] else 1
 
     def _restrict(self, l):
@@ -237,8 +250,6 @@ class SlabMultigrid:
         o, Ls = self.ops, self.plan.levels
         self._exchange([(self.r[l], Ls[l], 1)], up=True, down=False)
         o.restrict(self.r[l], Ls[l].nx, self.b[l + 1], Ls[l + 1].nx, Ls[l + 1].t0, Ls[l + 1].t1, 0, Ls[l].oj)
-        if self.fused and l + 1 < self.n_para:
-            self._exchange([(self.b[l + 1], Ls[l + 1], min(self.plan.halo, 6))])
 
     def _tail(self):
         """Whole-domain levels on rank 0 (parallel_multigrid.py:291-304)."""
@@ -315,11 +326,9 @@ class SlabMultigrid:
     def _cycle(self):
         """One V-cycle (the body of the loop at parallel_multigrid.py:270-347), norm included."""
         n_para = self.n_para
-        # ---- descent
-        self._restrict(0)
+        # ---- descent (b_1 was produced together with the finest residual, by presmooth or the last cycle)
         for l in range(1, n_para):
-            self._smooth(l, None, None, self.N1, self.r[l])
-            self._restrict(l)
+            self._smooth(l, None, None, self.N1, None if self.fused else self.r[l], restrict=True)
         # ---- coarse
         corr = self._coarse_solve()
         # ---- ascent

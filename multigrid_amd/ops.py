@@ -82,14 +82,19 @@ class HipOps:
 
     supports_fused = True
 
-    def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None):
-        """[x_in += P(crs)] -> `sweeps` Jacobi sweeps -> [residual]; x_in None = start from zero."""
-        check(self.L.mg_smooth_fused(b.data_ptr(), x_in.data_ptr() if x_in is not None else None, x_out.data_ptr(),
-                                     r.data_ptr() if r is not None else None,
-                                     crs.data_ptr() if crs is not None else None, x_out.shape[0], nx, x_out.stride(0),
-                                     crs.shape[0] if crs is not None else 0, cnx,
-                                     crs.stride(0) if crs is not None else 0, j0, j1, fix_lo, fix_hi, oj, sweeps, h,
-                                     norm.data_ptr() if norm is not None else None, self._s))
+    def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
+                     coarse_b=None, cbnx=0, T0=0, T1=0):
+        """[x_in += P(crs)] -> `sweeps` Jacobi sweeps -> [residual] -> [restriction into coarse_b];
+        x_in None = start from zero."""
+        p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        common = (p(b), p(x_in), p(x_out), p(r), p(crs), x_out.shape[0], nx, x_out.stride(0),
+                  crs.shape[0] if crs is not None else 0, cnx, crs.stride(0) if crs is not None else 0, j0, j1,
+                  fix_lo, fix_hi, oj, sweeps, h, p(norm))
+        if coarse_b is None:
+            check(self.L.mg_smooth_fused(*common, self._s))
+        else:
+            check(self.L.mg_smooth_fused_restrict(*common, p(coarse_b), coarse_b.shape[0], cbnx, coarse_b.stride(0), T0,
+                                                  T1, self._s))
 
     def sor(self, b, x, r, nx, h, iterations, ordering):
         check(self.L.mg_sor(b.data_ptr(), x.data_ptr(), r.data_ptr() if r is not None else None, x.shape[0], nx,

@@ -80,18 +80,24 @@ class OracleOps:
     def prolong_add(self, c, cnx, f, fnx, t0, t1, oi, oj):
         fc = np.ascontiguousarray(f.numpy()[:, :fnx])
         if oj in (0, -1):
-            cc, o2 = np.ascontiguousarray(c.numpy()[:, :cnx]), oj
-        else:  # fine row t <-> coarse row (t - oj) / 2: drop the first -oj/2 coarse rows, offset 0
+            oracle.interpolate_add_to(np.ascontiguousarray(c.numpy()[:, :cnx]), fc, oi, oj)
+        else:
+            # fine row t <-> coarse row (t - oj) / 2.  Drop the first -oj/2 - 1 coarse rows and put two
+            # spare rows in front of the fine array: then fine row t+2 <-> coarse row' (t+2)/2, offset 0,
+            # and fine row 0 is still reached (the oracle's passes start at fine row 1).
             assert oj % 2 == 0
-            s = -oj // 2
-            n = min(c.shape[0] - s, (fc.shape[0] + 2) // 2)
-            cc, o2 = np.ascontiguousarray(c.numpy()[s : s + n, :cnx]), 0
-        oracle.interpolate_add_to(cc, fc, oi, o2)
+            s = -oj // 2 - 1
+            fp = np.zeros((fc.shape[0] + 2, fnx))
+            fp[2:] = fc
+            n = min(c.shape[0] - s, (fp.shape[0] + 2) // 2)
+            oracle.interpolate_add_to(np.ascontiguousarray(c.numpy()[s : s + n, :cnx]), fp, oi, 0)
+            fc = fp[2:]
         f.numpy()[t0:t1, 1 : fnx - 1] = fc[t0:t1, 1 : fnx - 1]
 
     supports_fused = True
 
-    def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None):
+    def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
+                     coarse_b=None, cbnx=0, T0=0, T1=0):
         """The fused pass as the sequence it stands for: prolong_add, `sweeps` Jacobi sweeps, residual
         (rows between the fixed rows are the interior; only rows j0..j1-1 are written back)."""
         ny = x_out.shape[0]
@@ -106,6 +112,11 @@ class OracleOps:
         x_out[j0:j1] = cur[j0:j1]
         if r is not None:
             self.residual(r, cur, b, nx, j0, j1, h, norm)
+        if coarse_b is not None:
+            # the residual on every row a sweep may touch (halo rows included), Dirichlet cells as r holds them
+            rt = r.clone() if r is not None else torch.zeros_like(x_out)
+            self.residual(rt, cur, b, nx, lo, hi, h, norm if r is None else None)
+            self.restrict(rt, nx, coarse_b, cbnx, T0, T1, 0, oj)
 
     def sor(self, b, x, r, nx, h, iterations, ordering):
         xs = np.ascontiguousarray(x.numpy()[:, :nx])

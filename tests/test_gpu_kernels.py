@@ -468,3 +468,57 @@ def test_fused_pass_partial_rows(L):
     assert np.array_equal(got[60:131], ref[60:131])
     got[60:131] = 5.0
     assert np.all(got == 5.0)
+
+
+@pytest.mark.parametrize("shape", [(40, 121), (70, 249), (300, 257), (130, 1001), (600, 2051)], ids=str)
+@pytest.mark.parametrize("sweeps", [1, 3, 6])
+@pytest.mark.parametrize("mode", ["plain", "zero", "prolong"])
+@pytest.mark.parametrize("store_r", [True, False])
+def test_fused_restriction_equals_separate_kernels(L, shape, sweeps, mode, store_r):
+    """mg_smooth_fused_restrict == mg_smooth_fused followed by mg_restrict, bit for bit, whether or
+    not the residual itself is stored."""
+    import ctypes as C
+    import torch
+    ny, nx = shape
+    rng = np.random.default_rng(ny + 7 * nx + sweeps)
+    h = 0.3
+    x = rng.standard_normal(shape)
+    b = rng.standard_normal(shape)
+    if mode == "zero":
+        x[:] = 0
+    flo, fhi, j0, j1 = 1, ny - 1, 2, ny - 1
+    R = ny - 2
+    assert R % 2 == 0 and nx % 2 == 1
+    cny, cnx = R // 2 + 2, (nx - 1) // 2 + 1
+    c = rng.standard_normal((cny, cnx)) if mode == "prolong" else None
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    db, dx = padded(b), padded(x)
+    ld = dx.stride(0)
+    dc = padded(c) if c is not None else None
+    z = np.zeros(shape)
+    zc = np.zeros((cny, cnx))
+    args = (db.data_ptr(), None if mode == "zero" else dx.data_ptr())
+    cargs = (dc.data_ptr() if c is not None else None, ny, nx, ld, cny if c is not None else 0,
+             cnx if c is not None else 0, dc.stride(0) if c is not None else 0, j0, j1, flo, fhi, -1, sweeps, h)
+    # separate: fused smoothing + residual, then the restriction kernel
+    o1, r1, cb1 = padded(x), padded(z), padded(zc)
+    s1 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
+    L.check(lib.mg_smooth_fused(*args, o1.data_ptr(), r1.data_ptr(), *cargs, s1.data_ptr(), st))
+    L.check(lib.mg_restrict(r1.data_ptr(), ny, nx, ld, cb1.data_ptr(), cny, cnx, cb1.stride(0), 2, cny - 1, 0, -1, 1, 0, 0,
+                            st))
+    # fused
+    o2, r2, cb2 = padded(x), padded(z), padded(zc)
+    s2 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
+    L.check(lib.mg_smooth_fused_restrict(*args, o2.data_ptr(), r2.data_ptr() if store_r else None, *cargs, s2.data_ptr(),
+                                         cb2.data_ptr(), cny, cnx, cb2.stride(0), 2, cny - 1, st))
+    assert np.array_equal(o2.cpu().numpy(), o1.cpu().numpy())
+    assert np.array_equal(cb2.cpu().numpy(), cb1.cpu().numpy())
+    n1, n2 = C.c_double(), C.c_double()
+    L.check(lib.mg_norm_read(s1.data_ptr(), C.byref(n1), st))
+    L.check(lib.mg_norm_read(s2.data_ptr(), C.byref(n2), st))
+    assert n1.value == n2.value
+    if store_r:
+        assert np.array_equal(r2.cpu().numpy(), r1.cpu().numpy())
+    else:
+        assert not r2.cpu().numpy().any()
