@@ -45,8 +45,11 @@ __device__ __forceinline__ double lane_bcast(double v, int src)
                             __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
+// The deepest pipelines sit just above the register count that still lets three waves share a SIMD
+// (168 VGPRs); asking for three keeps them there, and occupancy is what hides the HBM latency.
 template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
-__global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
+__global__ __launch_bounds__(256, (U == 1 && (K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0)) >= 7) ? 3 : 1)
+void mg_fused_kernel(const FusedArgs a)
 {
     static_assert(!RESTRICT || RESID, "the restriction consumes the residual stage");
     constexpr int D = K + (RESID ? 1 : 0);   // pipeline stages that hold a three-row window
