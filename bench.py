@@ -14,9 +14,10 @@ launched by torch.distributed.run) every rank keeps that slab and the global gri
 whole-domain levels are gathered onto rank 0.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the dominant kernel (finest-level Jacobi sweep): algorithmic bytes per launch
-                (24 B per updated point) / its average duration, timed here with HIP events on the
-                stream the kernel runs on, against the 8 TB/s HBM peak
+  roofline      the dominant kernel (the finest level's fused pass: prolongation, 6 Jacobi sweeps,
+                residual, max-norm and restriction in one launch): algorithmic bytes per launch / its
+                average duration, timed here with HIP events on the stream the kernel runs on, against
+                the 8 TB/s HBM peak; the plain Jacobi sweep (24 B per point) is reported beside it
   cpu_baseline  the CPU oracle (C restatement of the reference algorithm, OpenMP over rows) timed
                 on this host's cores on a bounded sample (a smaller grid, a few V-cycles)
 """
@@ -195,16 +196,19 @@ def main():
               "algorithmic_bytes_per_launch": 24 * pts_launch, "achieved": 24 * pts_launch / (sweep_ms * 1e-3) / 1e9}
     single["frac"] = single["achieved"] / HBM_PEAK_GBPS
     if eng.fused:
-        crs = eng._xa[1] if n_para > 1 else eng.b[1]
+        crs = eng._xa[1] if n_para > 1 else (eng._xw0_pad if world == 1 else eng._corr)
+        # exactly the launch the cycle makes on the finest level: prolongation + 6 sweeps + residual + max-norm
+        # + full-weighting restriction of that residual into the next level's right-hand side.  The timed
+        # launches overwrite r_0 and b_1 with what the next cycle would compute anyway; x ping-pongs.
         pass_ms = timed(lambda k: ops.smooth_fused(eng.b[0], xs[k & 1], xs[1 - (k & 1)], eng.r[0], crs, L0.nx, L1.nx,
-                                                   L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, L0.h, eng.norm))
-        dom_name = "mg_fused_kernel<6, true, false, true, 1> (finest level: prolongation + 6 Jacobi sweeps + residual)"
+                                                   L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, L0.h, eng.norm,
+                                                   eng.b[1], L1.nx, L1.t0, L1.t1))
+        dom_name = ("mg_fused_kernel<6, true, false, true, true, 1> (finest level: prolongation + 6 Jacobi sweeps + "
+                    "residual + max-norm + restriction)")
         dom_ms = pass_ms
-        alg_bpp = 18 + 6 * 24 + 24   # the units one launch processes, at SURVEY 8(d)'s per-unit bytes
-        own_bpp = 8 + 2 + 8 + 8 + 8  # what the pass itself must move: R x, R coarse, R b, W x, W r
+        alg_bpp = 18 + 6 * 24 + 24 + 10  # per-operation compulsory bytes x the operations this launch performs
+        own_bpp = 8 + 2 + 8 + 8 + 8 + 2  # what the pass itself must move: R x, R coarse x, R b, W x, W r, W coarse b
         tkey = "fused_finest_bytes_per_launch"
-    else:
-        dom_name, dom_ms, alg_bpp, own_bpp, tkey = single["kernel"], sweep_ms, 24, 24, "jacobi_finest_bytes_per_launch"
     alg_bytes_launch = alg_bpp * pts_launch
     achieved = alg_bytes_launch / (dom_ms * 1e-3) / 1e9
 

@@ -416,6 +416,9 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
                    (long long)cnx);
     }
     if (coarse_b) {
+        MG_REQUIRE((const double *)coarse_b != crs && (const double *)coarse_b != b && coarse_b != x_out && coarse_b != r &&
+                       (const double *)coarse_b != x_in,
+                   "mg_smooth_fused_restrict: the coarse right-hand side aliases another array of the pass");
         MG_REQUIRE(ofst_j <= 0 && cbny >= 3 && cbnx >= 3 && cbld >= cbnx, "mg_smooth_fused_restrict: bad coarse shape");
         MG_REQUIRE(T0 >= 1 && T1 <= cbny - 1 && T0 <= T1, "mg_smooth_fused_restrict: coarse rows [%lld, %lld) outside 1..%lld",
                    (long long)T0, (long long)T1, (long long)(cbny - 1));

@@ -103,6 +103,9 @@ class SlabMultigrid:
         if world > 1:
             self._gather_buf = z(world * S.ny, S.ld) if rank == 0 else None
             self._scatter_buf = z(world * S.ny, S.ld) if rank == 0 else None
+            # the correction lands in a slab of its own: with one Jacobi level the pass that prolongs it
+            # also writes the staging level's right-hand side
+            self._corr = z(S.ny, S.ld)
         self._graphs = {}
         self._tail_graph = None
         self._b0_halo_valid = False
@@ -307,11 +310,11 @@ class SlabMultigrid:
                 win = self._xw0_pad.as_strided((self.world, S.ny, S.ld), (R * S.ld, S.ld, 1))
                 self._scatter_buf.view(self.world, S.ny, S.ld).copy_(win)
             parts = list(self._scatter_buf.view(self.world, S.ny, S.ld).unbind(0))
-            self.comm.scatter0(stage, parts)
+            self.comm.scatter0(self._corr, parts)
         else:
             self.comm.gather0(stage, None)
-            self.comm.scatter0(stage, None)
-        return stage
+            self.comm.scatter0(self._corr, None)
+        return self._corr
 
     def _run_tail(self):
         if not self.use_graph or self.world == 1:  # on one rank the tail is part of the cycle graph

@@ -148,7 +148,7 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 65, 65, 2, True), (2, 129, 65, 3, True), (2, 129, 65, 3, False),
+@pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 65, 65, 2, True), (2, 65, 33, 1, True), (2, 129, 65, 3, True), (2, 129, 65, 3, False),
                                                         (4, 129, 129, 3, True), (4, 257, 33, 2, True),
                                                         (4, 257, 33, 2, False)], ids=str)
 def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused):

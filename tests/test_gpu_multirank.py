@@ -45,7 +45,7 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 257, 257, 3, True), (4, 1025, 513, 5, True),
+@pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 257, 257, 3, True), (2, 129, 97, 1, True), (4, 1025, 513, 5, True),
                                                         (3, 769, 300 * 4 + 1, 2, True), (4, 1025, 513, 5, False)], ids=str)
 def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para, fused):
     import torch.multiprocessing as mp

@@ -32,6 +32,7 @@ def main():
     b = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
     c = torch.rand((L1.ny, L1.ld), dtype=torch.float64, device="cuda")
     r = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
+    cb = torch.rand((L1.ny, L1.ld), dtype=torch.float64, device="cuda")
     slots = ops.norm_slots()
     torch.cuda.synchronize()
     ops.begin()
@@ -44,6 +45,11 @@ def main():
         ops.smooth_fused(b, x, y, r, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, 0.5, slots)
         ops.smooth_fused(b, None, y, r, None, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 3, 0.5, None)
         ops.smooth_fused(b, x, y, None, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, 0.5, None)
+        # the two passes the cycle runs with the restriction fused in (finest level; descent of a coarser one)
+        ops.smooth_fused(b, x, y, r, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, 0.5, slots,
+                         cb, L1.nx, L1.t0, L1.t1)
+        ops.smooth_fused(b, None, y, None, None, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 3, 0.5, None,
+                         cb, L1.nx, L1.t0, L1.t1)
         ops.synchronize()
         print(f"rep {k} done", flush=True)
     pts = (L0.t1 - L0.t0) * (L0.nx - 2)
