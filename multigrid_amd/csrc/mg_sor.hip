@@ -137,6 +137,147 @@ __global__ __launch_bounds__(1024) void mg_sor_wavefront_kernel(const double *__
 #undef XW
 }
 
+// ---- single-wave wavefront -------------------------------------------------------------------
+// For grids of at most 64*RPL+1 rows one wave walks the whole wavefront without any barrier:
+// lane l owns rows RPL*l+1 .. RPL*l+RPL and every row advances one column per step, row j being at
+// column d-j at step d (d descending in the backward sweep).  What a cell needs from the rows
+// above and below sits in registers of the same lane or of the neighbouring lane:
+//   forward   above (new) = the value the row above produced one step ago, below (old) = the value
+//             the row below has just loaded as its own next cell;
+//   backward  the same with the roles of above and below exchanged.
+// The values cross the lane seam by DPP wave shifts, so the dependent chain of a step is two lane
+// shifts and a handful of FP64 operations.  LDS keeps the grid between sweeps; a lane reads and
+// writes only its own rows there (plus the constant top boundary row), SORW_PF steps ahead of use,
+// like b from global memory.  Rows beyond the last interior row (the bottom boundary row included)
+// stream their values without being updated, which supplies the bottom boundary to the row above.
+// The remaining waves of the workgroup only help to load the grid and to write x and r back.
+#define SORW_PF 8
+
+template <int RPL, int DIR>
+__device__ __forceinline__ void sor_wave_sweep(const double *__restrict__ b, double *sx, int ny, int nx, i64 ld, int ldl,
+                                               double h2, int lane)
+{
+    const double a = 1.5, alpha = 1 - a, beta = a / 4;
+    int j[RPL];
+    bool strm[RPL], inter[RPL];
+    double *srow[RPL];
+    const double *brow[RPL];
+    double self[RPL], lat[RPL];
+    constexpr int PF = RPL >= 4 ? 4 : SORW_PF;
+    double aq[RPL][PF], bq[RPL][PF], tq[PF]; // the chunk of PF steps being computed
+    double an[RPL][PF], bn[RPL][PF], tn[PF]; // the next chunk, in flight
+    const int d0 = DIR > 0 ? 1 : ny + nx - 2;                 // first step: row 1 at column 0 / row ny-1 at column nx-1
+    const int nsteps = DIR > 0 ? ny + nx - 4 : ny + nx - 3;   // last step: row ny-2 at column nx-2 / row 1 at column 1
+    const int clo = DIR > 0 ? 0 : 1, chi = DIR > 0 ? nx - 2 : nx - 1; // columns at which a row shifts its window
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        j[k] = RPL * lane + 1 + k;
+        strm[k] = j[k] <= ny - 1;
+        inter[k] = j[k] <= ny - 2;
+        srow[k] = sx + (j[k] < ny - 1 ? j[k] : ny - 1) * ldl;
+        brow[k] = b + (i64)(j[k] < ny - 1 ? j[k] : ny - 1) * ld;
+        self[k] = srow[k][DIR > 0 ? 0 : nx - 1];
+        lat[k] = 0;
+    }
+    // all loads are unconditional with clamped (always valid) addresses; a value loaded for a column
+    // outside the row's range is never used
+    auto fetch = [&](double (&qa)[RPL][PF], double (&qb)[RPL][PF], double (&qt)[PF], int dc) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int d = dc + DIR * u;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                const int c = d - j[k];
+                int ca = c + DIR, cb = c;
+                ca = ca < 0 ? 0 : (ca > nx - 1 ? nx - 1 : ca);
+                cb = cb < 0 ? 0 : (cb > nx - 1 ? nx - 1 : cb);
+                qa[k][u] = srow[k][ca];
+                qb[k][u] = brow[k][cb];
+            }
+            int c0 = d - 1;
+            c0 = c0 < 0 ? 0 : (c0 > nx - 1 ? nx - 1 : c0);
+            qt[u] = sx[c0];
+        }
+    };
+    fetch(aq, bq, tq, d0);
+    for (int t0 = 0; t0 < nsteps; t0 += PF) {
+        fetch(an, bn, tn, d0 + DIR * (t0 + PF)); // used PF .. 2*PF-1 steps from now
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int d = d0 + DIR * (t0 + u); // steps past the last one update nothing: no row is in range
+            double ahead[RPL], bv[RPL], above[RPL], below[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) ahead[k] = aq[k][u], bv[k] = bq[k][u];
+            const double top = tq[u];
+            if (DIR > 0) {
+                const double p = wave_from_prev(lat[RPL - 1]);
+                above[0] = lane == 0 ? top : p;
+                below[RPL - 1] = wave_from_next(ahead[0]);
+#pragma unroll
+                for (int k = 1; k < RPL; ++k) above[k] = lat[k - 1], below[k - 1] = ahead[k];
+            } else {
+                const double p = wave_from_prev(ahead[RPL - 1]);
+                above[0] = lane == 0 ? top : p;
+                below[RPL - 1] = wave_from_next(lat[0]);
+#pragma unroll
+                for (int k = 1; k < RPL; ++k) above[k] = ahead[k - 1], below[k - 1] = lat[k];
+            }
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                const int c = d - j[k];
+                const bool inr = strm[k] && c >= clo && c <= chi;
+                const bool act = inter[k] && c >= 1 && c <= nx - 2;
+                const double E = DIR > 0 ? ahead[k] : lat[k];
+                const double W = DIR > 0 ? lat[k] : ahead[k];
+                double v = alpha * self[k] + beta * (E + W + below[k] + above[k] - h2 * bv[k]);
+                v = act ? v : self[k];
+                if (act) srow[k][c] = v;
+                lat[k] = inr ? v : lat[k];
+                self[k] = inr ? ahead[k] : self[k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            tq[u] = tn[u];
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) aq[k][u] = an[k][u], bq[k][u] = bn[k][u];
+        }
+    }
+}
+
+template <int RPL>
+__global__ __launch_bounds__(256) void mg_sor_wave_kernel(const double *__restrict__ b, double *x,
+                                                          double *__restrict__ r, int ny, int nx, i64 ld, int ldl,
+                                                          double h2, int iterations, int backward, i64 bstride)
+{
+    extern __shared__ double sx[];
+    b += (i64)blockIdx.x * bstride;
+    x += (i64)blockIdx.x * bstride;
+    if (r) r += (i64)blockIdx.x * bstride;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int j = wv; j < ny; j += 4)
+        for (int i = lane; i < nx; i += 64) sx[j * ldl + i] = x[j * ld + i];
+    __syncthreads();
+    if (wv == 0) {
+        for (int it = 0; it < iterations; ++it) {
+            sor_wave_sweep<RPL, 1>(b, sx, ny, nx, ld, ldl, h2, lane);
+            if (backward) sor_wave_sweep<RPL, -1>(b, sx, ny, nx, ld, ldl, h2, lane);
+        }
+    }
+    __syncthreads();
+    const double hh = 1 / h2;
+    for (int j = wv; j < ny; j += 4)
+        for (int i = lane; i < nx; i += 64) {
+            const double c = sx[j * ldl + i];
+            x[j * ld + i] = c;
+            if (r && j >= 1 && j <= ny - 2 && i >= 1 && i <= nx - 2) {
+                const double left = sx[j * ldl + i - 1] * hh, cent = c * hh;
+                r[j * ld + i] = b[j * ld + i] - left -
+                                (sx[j * ldl + i + 1] + sx[(j - 1) * ldl + i] + sx[(j + 1) * ldl + i]) * hh + cent * 4;
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void mg_sor_rb_kernel(const double *__restrict__ b, double *x, i64 ny, i64 nx, i64 ld,
                                                         double h2, int colour, i64 bstride)
 {
@@ -151,6 +292,8 @@ __global__ __launch_bounds__(256) void mg_sor_rb_kernel(const double *__restrict
         }
     }
 }
+
+int g_sor_single_wave = 1; // tuning knob "sor_single_wave": 0 = never, 1 = where it is faster, 2 = wherever it fits
 
 extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64 ld, double h, i64 iterations,
                       int backward, int ordering, i64 nbatch, i64 bstride, void *stream)
@@ -170,6 +313,30 @@ extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64
         const bool lds = ny * (i64)ldl <= MG_SOR_LDS_DOUBLES;
         int nt = (int)(((ny - 2) + 63) / 64 * 64);
         if (nt > 1024) nt = 1024;
+        // measured: ahead of the one-thread-per-row kernel only with one row per lane and few grids in flight
+        if (lds && ny - 1 <= 64 * 4 && (g_sor_single_wave == 2 || (g_sor_single_wave == 1 && ny - 1 <= 64 && nbatch <= 256))) {
+            const size_t bytes = (size_t)ny * ldl * sizeof(double);
+            static bool wattr_set = false;
+            if (!wattr_set) {
+                const int cap = MG_SOR_LDS_DOUBLES * (int)sizeof(double);
+                MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                wattr_set = true;
+            }
+            const dim3 grid((unsigned)nbatch), block(256);
+            if (ny - 1 <= 64)
+                hipLaunchKernelGGL(mg_sor_wave_kernel<1>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, ld, ldl, h2,
+                                   (int)iterations, backward, bstride);
+            else if (ny - 1 <= 128)
+                hipLaunchKernelGGL(mg_sor_wave_kernel<2>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, ld, ldl, h2,
+                                   (int)iterations, backward, bstride);
+            else
+                hipLaunchKernelGGL(mg_sor_wave_kernel<4>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, ld, ldl, h2,
+                                   (int)iterations, backward, bstride);
+            MG_LAUNCH_CHECK("mg_sor (single-wave wavefront)");
+            return 0;
+        }
         if (lds) {
             const size_t bytes = (size_t)ny * ldl * sizeof(double);
             static bool attr_set = false;

@@ -263,22 +263,29 @@ def test_transfer_whole_domain(mm, fshape, cshape):
     assert np.array_equal(df.cpu().numpy(), f_ref)
 
 
-SOR_SHAPES = [(3, 3), (4, 7), (9, 9), (33, 33), (65, 257), (129, 129), (141, 139), (1100, 9), (257, 257), (1030, 40)]
+SOR_SHAPES = [(3, 3), (4, 7), (9, 9), (33, 33), (65, 257), (129, 129), (141, 139), (1100, 9), (257, 257), (1030, 40),
+              (65, 65), (66, 40), (64, 200), (5, 1000), (128, 128), (130, 90), (200, 90), (257, 65), (258, 20), (17, 3), (3, 17)]
 
 
 @pytest.mark.parametrize("shape", SOR_SHAPES, ids=str)
 @pytest.mark.parametrize("its", [1, 3])
-def test_sor_lexicographic_vs_oracle(mm, shape, its):
-    """Wavefront execution (LDS and global-memory variants) == row-major Gauss-Seidel, bit for bit."""
+@pytest.mark.parametrize("single_wave", [2, 0])
+def test_sor_lexicographic_vs_oracle(mm, L, shape, its, single_wave):
+    """Wavefront execution (one wave with lane shifts, one thread per row in LDS, global memory) ==
+    row-major Gauss-Seidel, bit for bit."""
     rng = np.random.default_rng(shape[0] * 7 + its)
     b, x0, r0 = rng.standard_normal(shape), rng.standard_normal(shape), rng.standard_normal(shape)
-    for fn in ("smooth", "smooth_altern"):
-        x_ref, r_ref = x0.copy(), r0.copy()
-        getattr(oracle, fn)(b, x_ref, 0.3, r_ref, its)
-        dx, dr = padded(x0), padded(r0)
-        getattr(mm, fn)(padded(b), dx, 0.3, dr, its)
-        assert np.array_equal(dx.cpu().numpy(), x_ref), fn
-        assert np.array_equal(dr.cpu().numpy(), r_ref), fn
+    L.check(L.lib().mg_set_tuning(b"sor_single_wave", single_wave))
+    try:
+        for fn in ("smooth", "smooth_altern"):
+            x_ref, r_ref = x0.copy(), r0.copy()
+            getattr(oracle, fn)(b, x_ref, 0.3, r_ref, its)
+            dx, dr = padded(x0), padded(r0)
+            getattr(mm, fn)(padded(b), dx, 0.3, dr, its)
+            assert np.array_equal(dx.cpu().numpy(), x_ref), fn
+            assert np.array_equal(dr.cpu().numpy(), r_ref), fn
+    finally:
+        L.check(L.lib().mg_set_tuning(b"sor_single_wave", 1))
 
 
 @pytest.mark.parametrize("shape", [(3, 3), (9, 9), (33, 65), (129, 129), (513, 513)], ids=str)
