@@ -21,6 +21,8 @@
 //
 // Arithmetic follows the reference's expression order (see include/mg_hip.h); compiled with
 // -ffp-contract=off.
+#include <type_traits>
+
 #include "mg_common.h"
 
 struct FusedArgs {
@@ -45,11 +47,35 @@ __device__ __forceinline__ double lane_bcast(double v, int src)
                             __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-// The deepest pipelines sit just above the register count that still lets three waves share a SIMD
-// (168 VGPRs); asking for three keeps them there, and occupancy is what hides the HBM latency.
+// Whole-wave shifts by one lane whose end lane (0 resp. 63) receives 0: no fallback operand, hence no
+// register copy in front of the DPP move.  Every use below either replaces the end lane's value or
+// lets it fall into columns the strip does not own.
+__device__ __forceinline__ double from_prev0(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next0(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int N>
+using int_c = std::integral_constant<int, N>;
+
+// The pass is bound by instruction issue as much as by memory (a row step of the 6-sweep pass with
+// residual and restriction needs ~110 FP64 operations and 32 lane shifts per wave), so the row loop
+// is written to add as little as possible to that:
+//  * the three-row windows are not shifted: the loop is unrolled by three and the slot a new row
+//    goes into rotates (step with rotation R overwrites slot R, the oldest row);
+//  * a wave whose strip and rows touch no Dirichlet cell and no array edge (almost all of them) runs
+//    a PLAIN instantiation without any of the per-cell selects;
+//  * row indices are 32-bit, so the uniform row tests are scalar compares.
 template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
-__global__ __launch_bounds__(256, (U == 1 && (K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0)) >= 7) ? 3 : 1)
-void mg_fused_kernel(const FusedArgs a)
+__global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
 {
     static_assert(!RESTRICT || RESID, "the restriction consumes the residual stage");
     constexpr int D = K + (RESID ? 1 : 0);   // pipeline stages that hold a three-row window
@@ -57,34 +83,51 @@ void mg_fused_kernel(const FusedArgs a)
     constexpr int Dv = (DC + 1) & ~1;
     constexpr int W = 128 * U;
     constexpr int STRIDE = W - 2 * Dv;
+    constexpr bool BL = D >= 5;                         // b ring in LDS
+    constexpr int NG = BL ? (D + 1) / 3 + 1 : 1;        // groups of three row slots: rows i-1 .. i-D plus the rotation slack
+    static_assert(K <= 6, "stages are instantiated up to 6 sweeps");
+    __shared__ double bring[BL ? 4 * NG * 3 * W : 1];
     int cb, rc;
     mg_tile_of_block((int)blockIdx.x, a.ncb, a.nrc, cb, rc);
     const int lane = threadIdx.x & 63;
     const int tile = cb * 4 + (threadIdx.x >> 6);
     const bool active = tile < a.ntc;
-    const i64 origin = (i64)(active ? tile : 0) * STRIDE;
-    const i64 own_lo = tile == 0 ? 0 : origin + Dv;
-    const i64 own_hi = origin + W - 1 >= a.nx - 1 ? ((a.nx - 1) | 1) : origin + W - 1 - Dv;
-    const i64 nx = a.nx, ld = a.ld;
+    const int origin = (active ? tile : 0) * STRIDE;
+    const int nx = (int)a.nx, ny = (int)a.ny, cnx = (int)a.cnx, cny = (int)a.cny;
+    const int flo = (int)a.flo, fhi = (int)a.fhi;
+    const i64 ld = a.ld;
+    const int own_lo = tile == 0 ? 0 : origin + Dv;
+    const int own_hi = origin + W - 1 >= nx - 1 ? ((nx - 1) | 1) : origin + W - 1 - Dv;
     const bool isR = lane == 63;
 
-    i64 c0[U], cl[U];
+    int c0[U];
+    unsigned cl[U];
     bool st[U], ic[U][2];
 #pragma unroll
     for (int g = 0; g < U; ++g) {
         c0[g] = origin + g * 128 + 2 * lane;
-        cl[g] = c0[g] + 2 <= ld ? c0[g] : ld - 2;
+        cl[g] = (unsigned)(c0[g] + 2 <= ld ? c0[g] : (int)ld - 2);
         st[g] = active && c0[g] >= own_lo && c0[g] + 1 <= own_hi && c0[g] + 2 <= ld;
         ic[g][0] = c0[g] >= 1 && c0[g] <= nx - 2;
         ic[g][1] = c0[g] + 1 >= 1 && c0[g] + 1 <= nx - 2;
     }
-    const i64 rb = a.j0 + (i64)rc * a.rpb;
-    const i64 re = rb + a.rpb < a.j1 ? rb + a.rpb : a.j1;
+    const int rb = (int)a.j0 + rc * a.rpb;
+    const int re = rb + a.rpb < (int)a.j1 ? rb + a.rpb : (int)a.j1;
     u64 nmax = 0;
 
     if (active && rb < re) { // uniform per wave
-        double w[D][3][U][2]; // w[s]: stage-s values of three consecutive rows (oldest first)
-        double br[D][U][2];   // br[d]: b of row i-1-d
+        double w[D][3][U][2]; // w[s]: stage-s values of three consecutive rows, slots rotating (see step)
+        // b of the rows in flight: row i-s for stage s.  Shallow pipelines shift it through registers
+        // (br[d]: b of row i-1-d).  Deep ones keep it in LDS instead, 28 VGPRs and 14 moves per step
+        // less: a ring of NG groups of three row slots per wave; a step with rotation R writes row i-1
+        // into slot R of the youngest group, so every slot a stage reads is a compile-time offset from
+        // one of NG base pointers, which change places once per three steps.
+        double br[BL ? 1 : D][U][2];
+        double *G[NG];
+        if constexpr (BL) {
+#pragma unroll
+            for (int k = 0; k < NG; ++k) G[k] = bring + ((threadIdx.x >> 6) * NG + k) * 3 * W + 2 * lane;
+        }
 #pragma unroll
         for (int s = 0; s < D; ++s)
 #pragma unroll
@@ -92,13 +135,13 @@ void mg_fused_kernel(const FusedArgs a)
 #pragma unroll
                 for (int g = 0; g < U; ++g) w[s][q][g][0] = w[s][q][g][1] = 0.0;
 #pragma unroll
-        for (int d = 0; d < D; ++d)
+        for (int d = 0; d < (BL ? 1 : D); ++d)
 #pragma unroll
             for (int g = 0; g < U; ++g) br[d][g][0] = br[d][g][1] = 0.0;
 
-        auto rowclamp = [&](i64 j) { return j < 0 ? (i64)0 : (j > a.ny - 1 ? a.ny - 1 : j); };
-        auto load_pairs = [&](const double *base, i64 j, double (&d)[U][2]) {
-            const double *row = base + rowclamp(j) * ld;
+        auto rowclamp = [&](int j) { return j < 0 ? 0 : (j > ny - 1 ? ny - 1 : j); };
+        auto load_pairs = [&](const double *base, int j, double (&d)[U][2]) {
+            const double *row = base + (i64)rowclamp(j) * ld;
 #pragma unroll
             for (int g = 0; g < U; ++g) {
                 double2 t = *reinterpret_cast<const double2 *>(row + cl[g]);
@@ -106,219 +149,289 @@ void mg_fused_kernel(const FusedArgs a)
             }
         };
         // coarse row J: value at coarse column c0/2 and at the next coarse column
-        auto load_coarse = [&](i64 J, double (&v0)[U], double (&v1)[U]) {
-            const i64 Jc = J < 0 ? 0 : (J > a.cny - 1 ? a.cny - 1 : J);
-            const double *row = a.crs + Jc * a.cld;
+        auto load_coarse = [&](int J, double (&v0)[U], double (&v1)[U]) {
+            const int Jc = J < 0 ? 0 : (J > cny - 1 ? cny - 1 : J);
+            const double *row = a.crs + (i64)Jc * a.cld;
 #pragma unroll
             for (int g = 0; g < U; ++g) {
-                const i64 q = c0[g] >> 1;
-                v0[g] = row[q > a.cnx - 1 ? a.cnx - 1 : q];
+                const int q = c0[g] >> 1;
+                v0[g] = row[(unsigned)(q > cnx - 1 ? cnx - 1 : q)];
             }
 #pragma unroll
             for (int g = 0; g < U; ++g) {
-                double nb = wave_from_next(v0[g]);
+                double nb = from_next0(v0[g]);
                 if (g + 1 < U) {
                     const double e = lane_bcast(v0[g + 1 < U ? g + 1 : 0], 0);
                     nb = isR ? e : nb;
                 } else {
-                    const i64 q1 = (c0[g] >> 1) + 1;
-                    const double e = isR ? row[q1 > a.cnx - 1 ? a.cnx - 1 : q1] : 0.0;
+                    const int q1 = (c0[g] >> 1) + 1;
+                    const double e = isR ? row[(unsigned)(q1 > cnx - 1 ? cnx - 1 : q1)] : 0.0;
                     nb = isR ? e : nb;
                 }
                 v1[g] = nb;
             }
         };
 
-        const i64 i0 = rb - DC, i1 = re + DC; // input rows streamed: i0 .. i1-1 (clamped into the array)
-        double rw[RESTRICT ? 3 : 1][U][2];    // residual rows i-K-3 .. i-K-1 (oldest first)
+        const int i0 = rb - DC, i1 = re + DC; // input rows streamed: i0 .. i1-1 (clamped into the array)
+        double rw[RESTRICT ? 3 : 1][U][2];    // residual rows, slots rotating like w
 #pragma unroll
         for (int q = 0; q < (RESTRICT ? 3 : 1); ++q)
 #pragma unroll
             for (int g = 0; g < U; ++g) rw[q][g][0] = rw[q][g][1] = 0.0;
-        double xn[U][2], bn[U][2];          // prefetched: x row i, b row i-1
-        if constexpr (!ZERO) load_pairs(a.xin, i0, xn);
-        load_pairs(a.b, i0 - 1, bn);
-        // coarse rows for the prolongation: cA = row J, cB = row J+1 of the current fine row
-        double cA0[U], cA1[U], cB0[U], cB1[U], cN0[U], cN1[U];
-        i64 Jh = 0;
+        // Loads run three row steps ahead of their use (slot q of the queues: x row i+q, b row i-1+q at
+        // the step whose rotation is 0): with few waves per SIMD that is what keeps enough bytes in flight.
+        double xq[3][U][2], bq[3][U][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if constexpr (!ZERO) load_pairs(a.xin, i0 + q, xq[q]);
+            load_pairs(a.b, i0 - 1 + q, bq[q]);
+        }
+        // coarse rows for the prolongation: cA = row J, cB = row J+1 of the current fine row, cN and cM
+        // the two after (loaded two to four steps before they become cB)
+        double cA0[U], cA1[U], cB0[U], cB1[U], cN0[U], cN1[U], cM0[U], cM1[U];
+        int Jh = 0;
         if constexpr (PROLONG) {
             Jh = (rowclamp(i0) - a.oj) >> 1;
             load_coarse(Jh, cA0, cA1);
             load_coarse(Jh + 1, cB0, cB1);
-#pragma unroll
-            for (int g = 0; g < U; ++g) cN0[g] = cB0[g], cN1[g] = cB1[g];
+            load_coarse(Jh + 2, cN0, cN1);
+            load_coarse(Jh + 3, cM0, cM1);
         }
+        const int oj = a.oj;
+        const double h2 = a.h2, hh = a.hh;
 
-        for (i64 i = i0; i < i1; ++i) {
-            // ---- take the prefetched rows, issue the loads of the next step
-            double y0[U][2], bcur[U][2];
-#pragma unroll
-            for (int g = 0; g < U; ++g) {
-                y0[g][0] = ZERO ? 0.0 : xn[g][0], y0[g][1] = ZERO ? 0.0 : xn[g][1];
-                bcur[g][0] = bn[g][0], bcur[g][1] = bn[g][1];
-            }
-            if constexpr (!ZERO) load_pairs(a.xin, i + 1, xn);
-            load_pairs(a.b, i, bn);
-            if constexpr (PROLONG) {
-                const i64 ic_ = rowclamp(i);
-                const i64 J = (ic_ - a.oj) >> 1;
-                if (J != Jh) { // uniform: at most one coarse row further
-#pragma unroll
-                    for (int g = 0; g < U; ++g) cA0[g] = cB0[g], cA1[g] = cB1[g], cB0[g] = cN0[g], cB1[g] = cN1[g];
-                    Jh = J;
-                }
-                const i64 Jn = (rowclamp(i + 1) - a.oj) >> 1;
-                if (Jn != Jh) load_coarse(Jn + 1, cN0, cN1); // needed from the next step on
-                if (i > a.flo && i < a.fhi && i >= 0 && i <= a.ny - 1) {
-                    const bool odd = (ic_ - a.oj) & 1;
-#pragma unroll
-                    for (int g = 0; g < U; ++g) {
-                        double add0, add1;
-                        if (odd) {
-                            add0 = (cA0[g] + cB0[g]) / 2;
-                            add1 = (cB1[g] + cB0[g] + cA1[g] + cA0[g]) / 4;
-                        } else {
-                            add0 = cA0[g];
-                            add1 = (cA0[g] + cA1[g]) / 2;
-                        }
-                        if (ic[g][0]) y0[g][0] += add0;
-                        if (ic[g][1]) y0[g][1] += add1;
-                    }
-                }
-            }
-            // ---- push stage 0 and b
-#pragma unroll
-            for (int g = 0; g < U; ++g)
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    w[0][0][g][v] = w[0][1][g][v], w[0][1][g][v] = w[0][2][g][v], w[0][2][g][v] = y0[g][v];
-#pragma unroll
-                    for (int d = D - 1; d > 0; --d) br[d][g][v] = br[d - 1][g][v];
-                    br[0][g][v] = bcur[g][v];
-                }
-            // ---- stages 1..K: stage s produces row i-s from the stage s-1 window
-#pragma unroll
-            for (int s = 1; s <= K; ++s) {
-                const i64 row = i - s;
-                const bool rint = row > a.flo && row < a.fhi;
-                double o[U][2];
+        // PL: no Dirichlet cell, no clamped row or column in anything this wave streams.
+        auto run = [&](auto plain_c) {
+            constexpr bool PL = decltype(plain_c)::value;
+            // One row step.  R = rotation: this step's new rows go into slot R of every window; after
+            // that the window's rows, oldest first, are slots A0, A1, A2.
+            auto step = [&](auto rot_c, const int i) {
+                constexpr int R = decltype(rot_c)::value;
+                constexpr int A0 = (R + 1) % 3, A1 = (R + 2) % 3, A2 = R;
+                // ---- take the prefetched rows, issue the loads of the next step
+                double bcur[U][2];
 #pragma unroll
                 for (int g = 0; g < U; ++g) {
-                    double west = wave_from_prev(w[s - 1][1][g][1]);
-                    double east = wave_from_next(w[s - 1][1][g][0]);
-                    if (g > 0) {
-                        const double t = lane_bcast(w[s - 1][1][g > 0 ? g - 1 : 0][1], 63);
-                        west = lane == 0 ? t : west;
-                    }
-                    if (g + 1 < U) {
-                        const double t = lane_bcast(w[s - 1][1][g + 1 < U ? g + 1 : 0][0], 0);
-                        east = isR ? t : east;
-                    }
-                    const double c0v = w[s - 1][1][g][0], c1v = w[s - 1][1][g][1];
-                    const double j0v = 0.25 * (c1v + west + w[s - 1][2][g][0] + w[s - 1][0][g][0] - a.h2 * br[s - 1][g][0]);
-                    const double j1v = 0.25 * (east + c0v + w[s - 1][2][g][1] + w[s - 1][0][g][1] - a.h2 * br[s - 1][g][1]);
-                    o[g][0] = (rint && ic[g][0]) ? j0v : c0v;
-                    o[g][1] = (rint && ic[g][1]) ? j1v : c1v;
+                    w[0][A2][g][0] = ZERO ? 0.0 : xq[R][g][0], w[0][A2][g][1] = ZERO ? 0.0 : xq[R][g][1];
+                    bcur[g][0] = bq[R][g][0], bcur[g][1] = bq[R][g][1];
                 }
-                if (s == K && row >= rb && row < re) {
-                    double *orow = a.xout + row * ld;
-#pragma unroll
-                    for (int g = 0; g < U; ++g)
-                        if (st[g]) *reinterpret_cast<double2 *>(orow + c0[g]) = make_double2(o[g][0], o[g][1]);
-                }
-                if (s < D) {
-#pragma unroll
-                    for (int g = 0; g < U; ++g)
-#pragma unroll
-                        for (int v = 0; v < 2; ++v)
-                            w[s][0][g][v] = w[s][1][g][v], w[s][1][g][v] = w[s][2][g][v], w[s][2][g][v] = o[g][v];
-                }
-            }
-            // ---- residual of row i-K-1 from the stage-K window
-            if constexpr (RESID) {
-                const i64 row = i - K - 1;
-                const bool mine = row >= rb && row < re;
-                const bool need = RESTRICT ? (row >= rb - 1 && row <= re) : mine; // uniform
-                if (need) {
-                    const bool rint = row > a.flo && row < a.fhi; // uniform
-                    double rv[U][2];
-                    if (rint) {
+                if constexpr (!ZERO) load_pairs(a.xin, i + 3, xq[R]);
+                load_pairs(a.b, i + 2, bq[R]);
+                if constexpr (PROLONG) {
+                    const int ic_ = rowclamp(i);
+                    const int J = (ic_ - oj) >> 1;
+                    if (J != Jh) { // uniform: at most one coarse row further
 #pragma unroll
                         for (int g = 0; g < U; ++g) {
-                            double west = wave_from_prev(w[K][1][g][1]);
-                            double east = wave_from_next(w[K][1][g][0]);
-                            if (g > 0) {
-                                const double t = lane_bcast(w[K][1][g > 0 ? g - 1 : 0][1], 63);
-                                west = lane == 0 ? t : west;
-                            }
-                            if (g + 1 < U) {
-                                const double t = lane_bcast(w[K][1][g + 1 < U ? g + 1 : 0][0], 0);
-                                east = isR ? t : east;
-                            }
-                            const double c0v = w[K][1][g][0], c1v = w[K][1][g][1];
-                            rv[g][0] = br[K][g][0] - west * a.hh - (c1v + w[K][0][g][0] + w[K][2][g][0]) * a.hh + (c0v * a.hh) * 4;
-                            rv[g][1] = br[K][g][1] - c0v * a.hh - (east + w[K][0][g][1] + w[K][2][g][1]) * a.hh + (c1v * a.hh) * 4;
-                            // cells outside the interior keep what r holds (the reference never writes
-                            // them); without an r array they are the zeros such an array would hold
-                            if (!(ic[g][0] && ic[g][1]) && (st[g] || RESTRICT)) {
-                                double2 keep = make_double2(0.0, 0.0);
-                                if (a.r) keep = *reinterpret_cast<const double2 *>(a.r + row * ld + cl[g]);
-                                if (!ic[g][0]) rv[g][0] = keep.x;
-                                if (!ic[g][1]) rv[g][1] = keep.y;
-                            }
+                            cA0[g] = cB0[g], cA1[g] = cB1[g], cB0[g] = cN0[g], cB1[g] = cN1[g];
+                            cN0[g] = cM0[g], cN1[g] = cM1[g];
                         }
-                        if (mine) {
+                        Jh = J;
+                        load_coarse(Jh + 3, cM0, cM1);
+                    }
+                    if (PL || (i > flo && i < fhi && i >= 0 && i <= ny - 1)) {
+                        const bool odd = (ic_ - oj) & 1;
 #pragma unroll
-                            for (int g = 0; g < U; ++g)
-                                if (st[g]) {
-                                    if (a.r) *reinterpret_cast<double2 *>(a.r + row * ld + c0[g]) = make_double2(rv[g][0], rv[g][1]);
-                                    if (ic[g][0]) {
+                        for (int g = 0; g < U; ++g) {
+                            double add0, add1;
+                            if (odd) {
+                                add0 = (cA0[g] + cB0[g]) / 2;
+                                add1 = (cB1[g] + cB0[g] + cA1[g] + cA0[g]) / 4;
+                            } else {
+                                add0 = cA0[g];
+                                add1 = (cA0[g] + cA1[g]) / 2;
+                            }
+                            if (PL || ic[g][0]) w[0][A2][g][0] += add0;
+                            if (PL || ic[g][1]) w[0][A2][g][1] += add1;
+                        }
+                    }
+                }
+                // ---- push b (row i-1)
+                if constexpr (BL) {
+#pragma unroll
+                    for (int g = 0; g < U; ++g)
+                        *reinterpret_cast<double2 *>(G[0] + R * W + g * 128) = make_double2(bcur[g][0], bcur[g][1]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < U; ++g)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+                            for (int d = D - 1; d > 0; --d) br[d][g][v] = br[d - 1][g][v];
+                            br[0][g][v] = bcur[g][v];
+                        }
+                }
+                // b of row i-s, for stage s
+                auto b_of = [&](auto s_c, double (&bs)[U][2]) {
+                    constexpr int s = decltype(s_c)::value;
+                    if constexpr (s == 1 || !BL) {
+#pragma unroll
+                        for (int g = 0; g < U; ++g)
+                            bs[g][0] = s == 1 ? bcur[g][0] : br[BL ? 0 : s - 1][g][0], bs[g][1] = s == 1 ? bcur[g][1] : br[BL ? 0 : s - 1][g][1];
+                    } else {
+                        constexpr int dl = R - s + 1;                     // slot relative to the youngest group's first
+                        constexpr int grp = dl >= 0 ? 0 : (-dl + 2) / 3;
+                        constexpr int sub = dl + 3 * grp;
+                        static_assert(grp < NG && sub >= 0 && sub < 3, "b ring too short");
+#pragma unroll
+                        for (int g = 0; g < U; ++g) {
+                            const double2 t = *reinterpret_cast<const double2 *>(G[grp] + sub * W + g * 128);
+                            bs[g][0] = t.x, bs[g][1] = t.y;
+                        }
+                    }
+                };
+                // ---- stages 1..K: stage s produces row i-s from the stage s-1 window
+                auto stage = [&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
+                    const int row = i - s;
+                    const bool rint = PL || (row > flo && row < fhi);
+                    double o[U][2], bs[U][2];
+                    b_of(s_c, bs);
+#pragma unroll
+                    for (int g = 0; g < U; ++g) {
+                        double west = from_prev0(w[s - 1][A1][g][1]);
+                        double east = from_next0(w[s - 1][A1][g][0]);
+                        if (g > 0) {
+                            const double t = lane_bcast(w[s - 1][A1][g > 0 ? g - 1 : 0][1], 63);
+                            west = lane == 0 ? t : west;
+                        }
+                        if (g + 1 < U) {
+                            const double t = lane_bcast(w[s - 1][A1][g + 1 < U ? g + 1 : 0][0], 0);
+                            east = isR ? t : east;
+                        }
+                        const double c0v = w[s - 1][A1][g][0], c1v = w[s - 1][A1][g][1];
+                        const double j0v = 0.25 * (c1v + west + w[s - 1][A2][g][0] + w[s - 1][A0][g][0] - h2 * bs[g][0]);
+                        const double j1v = 0.25 * (east + c0v + w[s - 1][A2][g][1] + w[s - 1][A0][g][1] - h2 * bs[g][1]);
+                        o[g][0] = (PL || (rint && ic[g][0])) ? j0v : c0v;
+                        o[g][1] = (PL || (rint && ic[g][1])) ? j1v : c1v;
+                    }
+                    if (s == K && row >= rb && row < re) {
+                        double *orow = a.xout + (i64)row * ld;
+#pragma unroll
+                        for (int g = 0; g < U; ++g)
+                            if (st[g]) *reinterpret_cast<double2 *>(orow + (unsigned)c0[g]) = make_double2(o[g][0], o[g][1]);
+                    }
+                    if constexpr (s < D) {
+#pragma unroll
+                        for (int g = 0; g < U; ++g) w[s][A2][g][0] = o[g][0], w[s][A2][g][1] = o[g][1];
+                    }
+                };
+                stage(int_c<1>{});
+                if constexpr (K >= 2) stage(int_c<2>{});
+                if constexpr (K >= 3) stage(int_c<3>{});
+                if constexpr (K >= 4) stage(int_c<4>{});
+                if constexpr (K >= 5) stage(int_c<5>{});
+                if constexpr (K >= 6) stage(int_c<6>{});
+                // ---- residual of row i-K-1 from the stage-K window
+                if constexpr (RESID) {
+                    const int row = i - K - 1;
+                    const bool mine = row >= rb && row < re;
+                    const bool need = RESTRICT ? (row >= rb - 1 && row <= re) : mine; // uniform
+                    if (need) {
+                        const bool rint = PL || (row > flo && row < fhi); // uniform
+                        double rv[U][2], bs[U][2];
+                        if (rint) {
+                            b_of(int_c<K + 1>{}, bs);
+#pragma unroll
+                            for (int g = 0; g < U; ++g) {
+                                double west = from_prev0(w[K][A1][g][1]);
+                                double east = from_next0(w[K][A1][g][0]);
+                                if (g > 0) {
+                                    const double t = lane_bcast(w[K][A1][g > 0 ? g - 1 : 0][1], 63);
+                                    west = lane == 0 ? t : west;
+                                }
+                                if (g + 1 < U) {
+                                    const double t = lane_bcast(w[K][A1][g + 1 < U ? g + 1 : 0][0], 0);
+                                    east = isR ? t : east;
+                                }
+                                const double c0v = w[K][A1][g][0], c1v = w[K][A1][g][1];
+                                rv[g][0] = bs[g][0] - west * hh - (c1v + w[K][A0][g][0] + w[K][A2][g][0]) * hh + (c0v * hh) * 4;
+                                rv[g][1] = bs[g][1] - c0v * hh - (east + w[K][A0][g][1] + w[K][A2][g][1]) * hh + (c1v * hh) * 4;
+                                // cells outside the interior keep what r holds (the reference never writes
+                                // them); without an r array they are the zeros such an array would hold
+                                if constexpr (!PL) {
+                                    if (!(ic[g][0] && ic[g][1]) && (st[g] || RESTRICT)) {
+                                        double2 keep = make_double2(0.0, 0.0);
+                                        if (a.r) keep = *reinterpret_cast<const double2 *>(a.r + (i64)row * ld + cl[g]);
+                                        if (!ic[g][0]) rv[g][0] = keep.x;
+                                        if (!ic[g][1]) rv[g][1] = keep.y;
+                                    }
+                                }
+                            }
+                            if (mine) {
+                                double *rrow = a.r + (i64)row * ld;
+#pragma unroll
+                                for (int g = 0; g < U; ++g) {
+                                    if (a.r && st[g]) *reinterpret_cast<double2 *>(rrow + (unsigned)c0[g]) = make_double2(rv[g][0], rv[g][1]);
+                                    // with one column pair per lane, lanes outside the owned columns are
+                                    // dropped once, after the loop
+                                    if ((U == 1 || st[g]) && (PL || ic[g][0])) {
                                         u64 key = (u64)__double_as_longlong(fabs(rv[g][0]));
                                         nmax = key > nmax ? key : nmax;
                                     }
-                                    if (ic[g][1]) {
+                                    if ((U == 1 || st[g]) && (PL || ic[g][1])) {
                                         u64 key = (u64)__double_as_longlong(fabs(rv[g][1]));
                                         nmax = key > nmax ? key : nmax;
                                     }
                                 }
+                            }
+                        } else if constexpr (RESTRICT) { // a Dirichlet row: r as stored
+#pragma unroll
+                            for (int g = 0; g < U; ++g) rv[g][0] = rv[g][1] = 0.0;
+                            if (a.r && row >= 0 && row <= ny - 1) load_pairs(a.r, row, rv);
                         }
-                    } else if constexpr (RESTRICT) { // a Dirichlet row: r as stored
+                        if constexpr (RESTRICT) {
 #pragma unroll
-                        for (int g = 0; g < U; ++g) rv[g][0] = rv[g][1] = 0.0;
-                        if (a.r && row >= 0 && row <= a.ny - 1) load_pairs(a.r, row, rv);
-                    }
-                    if constexpr (RESTRICT) {
+                            for (int g = 0; g < U; ++g) rw[A2][g][0] = rv[g][0], rw[A2][g][1] = rv[g][1];
+                            // full weighting of coarse row T, whose fine centre row is row-1 (owned by this
+                            // tile); the rows it reads, row-2 .. row, were all produced in `need` steps
+                            const int ctr = row - 1;
+                            if (ctr >= rb && ctr < re && ((ctr - oj) & 1) == 0) {
+                                const int T = (ctr - oj) >> 1;
+                                if (T >= (int)a.T0 && T < (int)a.T1) {
 #pragma unroll
-                        for (int g = 0; g < U; ++g)
-#pragma unroll
-                            for (int v = 0; v < 2; ++v)
-                                rw[0][g][v] = rw[1][g][v], rw[1][g][v] = rw[2][g][v], rw[2][g][v] = rv[g][v];
-                        // full weighting of coarse row T, whose fine centre row is row-1 (owned by this tile)
-                        const i64 ctr = row - 1;
-                        if (ctr >= rb && ctr < re && ((ctr - a.oj) & 1) == 0) {
-                            const i64 T = (ctr - a.oj) >> 1;
-                            if (T >= a.T0 && T < a.T1) {
-#pragma unroll
-                                for (int g = 0; g < U; ++g) {
-                                    const double a_right = rw[1][g][1] / 8 + (rw[2][g][1] + rw[0][g][1]) / 16;
-                                    double a_left = wave_from_prev(a_right);
-                                    if (g > 0) {
-                                        const double pr = rw[1][g > 0 ? g - 1 : 0][1] / 8 +
-                                                          (rw[2][g > 0 ? g - 1 : 0][1] + rw[0][g > 0 ? g - 1 : 0][1]) / 16;
-                                        const double t = lane_bcast(pr, 63);
-                                        a_left = lane == 0 ? t : a_left;
+                                    for (int g = 0; g < U; ++g) {
+                                        const double a_right = rw[A1][g][1] / 8 + (rw[A2][g][1] + rw[A0][g][1]) / 16;
+                                        double a_left = from_prev0(a_right);
+                                        if (g > 0) {
+                                            const double pr = rw[A1][g > 0 ? g - 1 : 0][1] / 8 +
+                                                              (rw[A2][g > 0 ? g - 1 : 0][1] + rw[A0][g > 0 ? g - 1 : 0][1]) / 16;
+                                            const double t = lane_bcast(pr, 63);
+                                            a_left = lane == 0 ? t : a_left;
+                                        }
+                                        double v = rw[A1][g][0] / 4 + (rw[A2][g][0] + rw[A0][g][0]) * 1 / 8;
+                                        v += a_right + a_left;
+                                        const int I = c0[g] >> 1;
+                                        if (st[g] && I >= 1 && I <= (int)a.cbnx - 2) a.cb[(i64)T * a.cbld + I] = v;
                                     }
-                                    double v = rw[1][g][0] / 4 + (rw[2][g][0] + rw[0][g][0]) * 1 / 8;
-                                    v += a_right + a_left;
-                                    const i64 I = c0[g] >> 1;
-                                    if (st[g] && I >= 1 && I <= a.cbnx - 2) a.cb[T * a.cbld + I] = v;
                                 }
                             }
                         }
                     }
                 }
+            };
+            int i = i0;
+            for (; i + 3 <= i1; i += 3) {
+                step(int_c<0>{}, i);
+                step(int_c<1>{}, i + 1);
+                step(int_c<2>{}, i + 2);
+                if constexpr (BL) { // the oldest group becomes the youngest
+                    double *const t = G[NG - 1];
+#pragma unroll
+                    for (int k = NG - 1; k > 0; --k) G[k] = G[k - 1];
+                    G[0] = t;
+                }
             }
-        }
+            if (i < i1) step(int_c<0>{}, i);
+            if (i + 1 < i1) step(int_c<1>{}, i + 1);
+        };
+        const bool plain = origin >= 1 && origin + W - 1 <= nx - 2 && origin + W <= ld && i0 - 1 > flo && i1 < fhi &&
+                           i0 - 1 >= 0 && i1 <= ny - 1;
+        if (plain)
+            run(std::true_type{});
+        else
+            run(std::false_type{});
+        if (U == 1 && !st[0]) nmax = 0; // only the owned columns count towards the norm
     }
     if constexpr (RESID) {
         if (a.norm) { // uniform
@@ -371,9 +484,13 @@ template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT>
 static int pick_u(const FusedArgs &a, hipStream_t st)
 {
     // deep pipelines keep D three-row windows per column pair in registers: one pair per lane then
-    int u = (K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0)) >= 5 ? 1 : g_fused_unroll;
-    while (u > 1 && a.nx < 128 * u) u >>= 1;
-    if (u == 2) return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 2>(a, st);
+    // two column pairs per lane halve the share of overlap columns but double the registers: worth it
+    // only for the shallowest pipelines
+    if constexpr (!PROLONG && (K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0) + (ZERO ? 0 : 1)) <= 3) {
+        int u = g_fused_unroll;
+        while (u > 1 && a.nx < 128 * u) u >>= 1;
+        if (u == 2) return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 2>(a, st);
+    }
     return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 1>(a, st);
 }
 

@@ -40,7 +40,8 @@ class SlabMultigrid:
 
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
-                 max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False):
+                 max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
+                 store_residual_every_cycle=False):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -109,6 +110,9 @@ class SlabMultigrid:
         self._graphs = {}
         self._tail_graph = None
         self._b0_halo_valid = False
+        self._r0_stale = False
+        # store the finest residual in every cycle's pass instead of once at the end of solve()/cycles()
+        self.store_residual_every_cycle = store_residual_every_cycle
 
     # ------------------------------------------------------------------ data access
     @property
@@ -122,7 +126,26 @@ class SlabMultigrid:
 
     @property
     def r0(self):
+        """Finest-level residual slab.  Fused passes compute the residual every cycle (for the norm and
+        the restriction) but do not store it; it is written when a solve()/cycles() call ends or on
+        demand (materialize_residual), with the values the per-cycle store would have left."""
+        if self._r0_stale:
+            if self.world > 1:
+                raise RuntimeError("the residual array is not current: call materialize_residual() on every rank")
+            self.materialize_residual()
         return self.r[0]
+
+    def materialize_residual(self):
+        """Write r = b - A x of the finest level for the current x (collective: one halo row of x is
+        exchanged).  A no-op when the last pass stored it."""
+        if not self._r0_stale:
+            return
+        L, x = self.plan.levels[0], self.x0
+        self.ops.begin()
+        self._exchange([(x, L, 1)])
+        self.ops.residual(self.r[0], x, self.b[0], L.nx, L.t0, L.t1, L.h, None, True)
+        self.ops.end()
+        self._r0_stale = False
 
     def owned_rows(self, level=0):
         """(first, last+1) local rows this rank owns, the global boundary rows included."""
@@ -244,8 +267,10 @@ class SlabMultigrid:
                 self._exchange([(self.b[0], self.plan.levels[0], self.plan.halo - 1)])
             self._b0_halo_valid = True
         # the residual of the finest level is restricted right away: b_1 is ready for the next descent
-        res = self._smooth(0, xs[self._cur0], crs, n, self.r[0], self.norm if want_norm else None, finest=True,
-                           crs_has_halo=self.n_para == 1, restrict=True)
+        store_r = self.store_residual_every_cycle or not self.fused
+        res = self._smooth(0, xs[self._cur0], crs, n, self.r[0] if store_r else None, self.norm if want_norm else None,
+                           finest=True, crs_has_halo=self.n_para == 1, restrict=True)
+        self._r0_stale = not store_r
         self._cur0 = 0 if res is xs[0] else 1
 
     def _restrict(self, l):
@@ -377,6 +402,7 @@ class SlabMultigrid:
             self._run_cycle()
             errs.append(self._global_err())
         self.ops.end()
+        self.materialize_residual()
         return errs
 
     def presmooth(self):
@@ -405,6 +431,7 @@ class SlabMultigrid:
             done = not (err > self.epsilon and not self.diverged)
             self.it += 1
         self.ops.end()
+        self.materialize_residual()
         return err
 
     def close(self):

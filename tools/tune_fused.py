@@ -29,7 +29,7 @@ def main():
     ops = HipOps()
     lib = _lib.lib()
     mk = lambda L: torch.rand((L.ny, L.ld), dtype=torch.float64, device="cuda")  # noqa: E731
-    x, y, b, r, c = mk(L0), mk(L0), mk(L0), mk(L0), mk(L1)
+    x, y, b, r, c, cb = mk(L0), mk(L0), mk(L0), mk(L0), mk(L1), mk(L1)
     slots = ops.norm_slots()
     pts = (L0.t1 - L0.t0) * (L0.nx - 2)
     torch.cuda.synchronize()
@@ -45,9 +45,10 @@ def main():
         ops.stream.synchronize()
         return e0.elapsed_time(e1) / args.iters
 
-    def f(k, pro, zero, res):
+    def f(k, pro, zero, res, rs=False):
         return lambda: ops.smooth_fused(b, None if zero else x, y, r if res else None, c if pro else None, L0.nx, L1.nx,
-                                        L0.t0, L0.t1, L0.t0 - 1, L0.t1, -1, k, 0.5, slots if res else None)
+                                        L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, k, 0.5, slots if (res or rs) else None,
+                                        cb if rs else None, L1.nx, L1.t0, L1.t1)
 
     # name: (compulsory bytes/pt of the pass, algorithmic bytes/pt of the separate kernels, fn)
     kernels = {
@@ -58,6 +59,10 @@ def main():
         "P+6J+R": (34, 18 + 144 + 24, f(6, True, False, True)),
         "P+6J": (26, 18 + 144, f(6, True, False, False)),
         "P+4J": (26, 18 + 96, f(4, True, False, False)),
+        "P+6J+RS": (28, 18 + 144 + 24 + 10, f(6, True, False, False, True)),
+        "P+6J+R+RS": (36, 18 + 144 + 24 + 10, f(6, True, False, True, True)),
+        "0+3J+RS": (18, 16 + 48 + 24 + 10, f(3, False, True, False, True)),
+        "1J+RS": (26, 24 + 24 + 10, f(1, False, False, False, True)),
     }
     configs = list(itertools.product(args.unroll, args.rows))
     results = {}
@@ -68,7 +73,7 @@ def main():
                 results.setdefault((cfg, name), []).append(timed(fn))
         print(f"round {rnd} done", flush=True)
     print(f"grid {N}x{N}; per kernel: median ms, TB/s of the pass's own compulsory bytes")
-    print(f"{'unr':>3} {'rows':>5} | " + " | ".join(f"{k:>14}" for k in kernels))
+    print(f"{'unr':>3} {'rows':>5} | " + " | ".join(f"{k:>14}" for k in kernels))  # noqa
     for cfg in configs:
         row = []
         for name, (bpp, _, _) in kernels.items():
