@@ -148,8 +148,10 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
                 d[g][0] = t.x, d[g][1] = t.y;
             }
         };
-        // coarse row J: value at coarse column c0/2 and at the next coarse column
-        auto load_coarse = [&](int J, double (&v0)[U], double (&v1)[U]) {
+        // Coarse row J as loaded: the value at coarse column c0/2 and, in lane 63 only, the value one
+        // coarse column beyond the strip.  Nothing is computed from them here, so the loads stay in
+        // flight; coarse_next() makes the second operand when the row comes into use.
+        auto load_coarse = [&](int J, double (&v0)[U], double &ve) {
             const int Jc = J < 0 ? 0 : (J > cny - 1 ? cny - 1 : J);
             const double *row = a.crs + (i64)Jc * a.cld;
 #pragma unroll
@@ -157,6 +159,11 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
                 const int q = c0[g] >> 1;
                 v0[g] = row[(unsigned)(q > cnx - 1 ? cnx - 1 : q)];
             }
+            const int q1 = (c0[U - 1] >> 1) + 1;
+            ve = isR ? row[(unsigned)(q1 > cnx - 1 ? cnx - 1 : q1)] : 0.0;
+        };
+        // value at the next coarse column: the neighbouring lane's, across the seam the next group's or ve
+        auto coarse_next = [&](const double (&v0)[U], const double ve, double (&v1)[U]) {
 #pragma unroll
             for (int g = 0; g < U; ++g) {
                 double nb = from_next0(v0[g]);
@@ -164,9 +171,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
                     const double e = lane_bcast(v0[g + 1 < U ? g + 1 : 0], 0);
                     nb = isR ? e : nb;
                 } else {
-                    const int q1 = (c0[g] >> 1) + 1;
-                    const double e = isR ? row[(unsigned)(q1 > cnx - 1 ? cnx - 1 : q1)] : 0.0;
-                    nb = isR ? e : nb;
+                    nb = isR ? ve : nb;
                 }
                 v1[g] = nb;
             }
@@ -186,16 +191,19 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
             if constexpr (!ZERO) load_pairs(a.xin, i0 + q, xq[q]);
             load_pairs(a.b, i0 - 1 + q, bq[q]);
         }
-        // coarse rows for the prolongation: cA = row J, cB = row J+1 of the current fine row, cN and cM
-        // the two after (loaded two to four steps before they become cB)
-        double cA0[U], cA1[U], cB0[U], cB1[U], cN0[U], cN1[U], cM0[U], cM1[U];
+        // coarse rows for the prolongation: cA = row J, cB = row J+1 of the current fine row; cN and cM
+        // are the two rows after, as loaded (two to four steps before they become cB)
+        double cA0[U], cA1[U], cB0[U], cB1[U], cN0[U], cNe = 0, cM0[U], cMe = 0;
         int Jh = 0;
         if constexpr (PROLONG) {
             Jh = (rowclamp(i0) - a.oj) >> 1;
-            load_coarse(Jh, cA0, cA1);
-            load_coarse(Jh + 1, cB0, cB1);
-            load_coarse(Jh + 2, cN0, cN1);
-            load_coarse(Jh + 3, cM0, cM1);
+            double e0, e1;
+            load_coarse(Jh, cA0, e0);
+            load_coarse(Jh + 1, cB0, e1);
+            load_coarse(Jh + 2, cN0, cNe);
+            load_coarse(Jh + 3, cM0, cMe);
+            coarse_next(cA0, e0, cA1);
+            coarse_next(cB0, e1, cB1);
         }
         const int oj = a.oj;
         const double h2 = a.h2, hh = a.hh;
@@ -222,12 +230,13 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
                     const int J = (ic_ - oj) >> 1;
                     if (J != Jh) { // uniform: at most one coarse row further
 #pragma unroll
-                        for (int g = 0; g < U; ++g) {
-                            cA0[g] = cB0[g], cA1[g] = cB1[g], cB0[g] = cN0[g], cB1[g] = cN1[g];
-                            cN0[g] = cM0[g], cN1[g] = cM1[g];
-                        }
+                        for (int g = 0; g < U; ++g) cA0[g] = cB0[g], cA1[g] = cB1[g], cB0[g] = cN0[g];
+                        coarse_next(cB0, cNe, cB1);
+#pragma unroll
+                        for (int g = 0; g < U; ++g) cN0[g] = cM0[g];
+                        cNe = cMe;
                         Jh = J;
-                        load_coarse(Jh + 3, cM0, cM1);
+                        load_coarse(Jh + 3, cM0, cMe);
                     }
                     if (PL || (i > flo && i < fhi && i >= 0 && i <= ny - 1)) {
                         const bool odd = (ic_ - oj) & 1;
@@ -281,12 +290,20 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
                     }
                 };
                 // ---- stages 1..K: stage s produces row i-s from the stage s-1 window
+                // b for stage s sits in bsq[s & 1]: each stage first issues the LDS read for the next one,
+                // so that the read's latency passes under this stage's arithmetic
+                double bsq[2][U][2];
+                b_of(int_c<1>{}, bsq[1]);
                 auto stage = [&](auto s_c) {
                     constexpr int s = decltype(s_c)::value;
                     const int row = i - s;
                     const bool rint = PL || (row > flo && row < fhi);
-                    double o[U][2], bs[U][2];
-                    b_of(s_c, bs);
+                    double o[U][2];
+                    if constexpr (s + 1 <= D) {
+                        b_of(int_c<s + 1>{}, bsq[(s + 1) & 1]);
+                        if constexpr (BL) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    double(&bs)[U][2] = bsq[s & 1];
 #pragma unroll
                     for (int g = 0; g < U; ++g) {
                         double west = from_prev0(w[s - 1][A1][g][1]);
@@ -329,9 +346,9 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
                     const bool need = RESTRICT ? (row >= rb - 1 && row <= re) : mine; // uniform
                     if (need) {
                         const bool rint = PL || (row > flo && row < fhi); // uniform
-                        double rv[U][2], bs[U][2];
+                        double rv[U][2];
+                        double(&bs)[U][2] = bsq[(K + 1) & 1];
                         if (rint) {
-                            b_of(int_c<K + 1>{}, bs);
 #pragma unroll
                             for (int g = 0; g < U; ++g) {
                                 double west = from_prev0(w[K][A1][g][1]);
@@ -469,7 +486,7 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     a.ncb = (a.ntc + 3) / 4;
     int rpb = g_fused_rows;
     if (rpb <= 0) {
-        rpb = 128;
+        rpb = 64; // measured at 32769 x 32769: 64-row tiles are as fast as or faster than taller ones at every depth
         while (rpb > 8 * D && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) < 2048) rpb >>= 1;
     }
     a.rpb = rpb;
