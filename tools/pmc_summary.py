@@ -35,9 +35,9 @@ BYTES = {
     "void mg_restrict_kernel<true>": (10, 10),
     "void mg_prolong_kernel<true, true>": (18, 18),
     "void mg_fused_kernel<6, true, false, true, false, 1>": (18 + 6 * 24 + 24, 8 + 2 + 8 + 8 + 8),
-    "void mg_fused_kernel<3, false, true, true, false, 2>": (16 + 2 * 24 + 24, 8 + 8 + 8),
+    "void mg_fused_kernel<3, false, true, true, false, 1>": (16 + 2 * 24 + 24, 8 + 8 + 8),
     "void mg_fused_kernel<6, true, false, false, false, 1>": (18 + 6 * 24, 8 + 2 + 8 + 8),
-    "void mg_fused_kernel<6, true, false, true, true, 1>": (18 + 6 * 24 + 24 + 10, 8 + 2 + 8 + 8 + 8 + 2),
+    "void mg_fused_kernel<6, true, false, true, true, 1>": (18 + 6 * 24 + 24 + 10, 8 + 2 + 8 + 8 + 2),  # r not stored
     "void mg_fused_kernel<3, false, true, true, true, 1>": (16 + 2 * 24 + 24 + 10, 8 + 8 + 2),
     "void mg_fused_kernel<3, false, true, true, true, 2>": (16 + 2 * 24 + 24 + 10, 8 + 8 + 2),
 }
