@@ -145,123 +145,151 @@ __global__ __launch_bounds__(1024) void mg_sor_wavefront_kernel(const double *__
 //   forward   above (new) = the value the row above produced one step ago, below (old) = the value
 //             the row below has just loaded as its own next cell;
 //   backward  the same with the roles of above and below exchanged.
-// The values cross the lane seam by DPP wave shifts, so the dependent chain of a step is two lane
-// shifts and a handful of FP64 operations.  LDS keeps the grid between sweeps; a lane reads and
-// writes only its own rows there (plus the constant top boundary row), SORW_PF steps ahead of use,
-// like b from global memory.  Rows beyond the last interior row (the bottom boundary row included)
-// stream their values without being updated, which supplies the bottom boundary to the row above.
+// The values cross the lane seam by DPP wave shifts.  A single wave issues one vector instruction
+// per ~4 cycles, so the step time IS the instruction count and the loop is kept to the arithmetic:
+//  * every row streams unconditionally (window shift without range tests): LDS has guard zones in
+//    front of and behind the grid, so reads beyond a row's ends are harmless and never used;
+//    b comes through a bounds-checked buffer resource (out-of-range reads return 0);
+//  * addresses advance by immediate offsets inside a chunk of SORW_PF steps; the loads of the next
+//    chunk are issued before the current one is computed (two chunks per loop iteration, no copies);
+//  * an inactive cell (boundary column, boundary row) keeps its value by one select and writes to a
+//    dummy slot instead of branching;
+//  * lane 0 takes the top boundary row as the fallback operand of the lane shift.
+// LDS keeps the grid between sweeps; a lane reads and writes only its own rows there (plus the
+// constant top boundary row).  Rows beyond the last interior row (the bottom boundary row included)
+// stream without being updated, which supplies the bottom boundary to the row above.
 // The remaining waves of the workgroup only help to load the grid and to write x and r back.
 #define SORW_PF 8
+#define SORW_GUARD 32      // doubles in front of the grid in LDS (reads run up to 3 chunks past a row's end)
+#define SORW_GUARD_BACK 96 // behind it: the same, plus one dummy slot per lane for the writes of inactive cells
 
 template <int RPL, int DIR>
-__device__ __forceinline__ void sor_wave_sweep(const double *__restrict__ b, double *sx, int ny, int nx, i64 ld, int ldl,
-                                               double h2, int lane)
+__device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, double *sx, double *dummy, int ny, int nx,
+                                               int ld, int ldl, double h2, int lane)
 {
+    constexpr int PF = SORW_PF;
     const double a = 1.5, alpha = 1 - a, beta = a / 4;
     int j[RPL];
-    bool strm[RPL], inter[RPL];
+    bool inter[RPL];
     double *srow[RPL];
-    const double *brow[RPL];
+    int boff[RPL];
     double self[RPL], lat[RPL];
-    constexpr int PF = RPL >= 4 ? 4 : SORW_PF;
-    double aq[RPL][PF], bq[RPL][PF], tq[PF]; // the chunk of PF steps being computed
-    double an[RPL][PF], bn[RPL][PF], tn[PF]; // the next chunk, in flight
-    const int d0 = DIR > 0 ? 1 : ny + nx - 2;                 // first step: row 1 at column 0 / row ny-1 at column nx-1
-    const int nsteps = DIR > 0 ? ny + nx - 4 : ny + nx - 3;   // last step: row ny-2 at column nx-2 / row 1 at column 1
-    const int clo = DIR > 0 ? 0 : 1, chi = DIR > 0 ? nx - 2 : nx - 1; // columns at which a row shifts its window
+    const int d0 = DIR > 0 ? 0 : ny + nx - 1;               // first step: row 1 at column -1 / row ny-1 at column nx
+    const int nsteps = DIR > 0 ? ny + nx - 3 : ny + nx - 2; // last step: row ny-2 at column nx-2 / row 1 at column 1
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         j[k] = RPL * lane + 1 + k;
-        strm[k] = j[k] <= ny - 1;
         inter[k] = j[k] <= ny - 2;
-        srow[k] = sx + (j[k] < ny - 1 ? j[k] : ny - 1) * ldl;
-        brow[k] = b + (i64)(j[k] < ny - 1 ? j[k] : ny - 1) * ld;
-        self[k] = srow[k][DIR > 0 ? 0 : nx - 1];
-        lat[k] = 0;
+        const int jc = j[k] < ny - 1 ? j[k] : ny - 1;
+        srow[k] = sx + jc * ldl;
+        boff[k] = jc * ld;
+        self[k] = 0, lat[k] = 0;
     }
-    // all loads are unconditional with clamped (always valid) addresses; a value loaded for a column
-    // outside the row's range is never used
-    auto fetch = [&](double (&qa)[RPL][PF], double (&qb)[RPL][PF], double (&qt)[PF], int dc) {
+    struct Chunk {
+        double ah[RPL][PF], bv[RPL][PF], top[PF];
+    };
+    // issue the loads of the PF steps starting at step t (column of row j: cb = d0 + DIR*t - j, then cb + DIR*u)
+    auto fetch = [&](Chunk &q, int t) {
+        const int dd = d0 + DIR * t;
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            const int cb = dd - j[k];
+            // forward: ahead = X(j, c+1), c = cb+u;  backward: ahead = X(j, c-1), c = cb-u  (offsets kept >= 0)
+            const double *pa = DIR > 0 ? srow[k] + cb + 1 : srow[k] + cb - 1 - (PF - 1);
+            const int ob = (boff[k] + (DIR > 0 ? cb : cb - (PF - 1))) * 8;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int w = DIR > 0 ? u : PF - 1 - u;
+                q.ah[k][u] = pa[w];
+                q.bv[k][u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(brs, ob + w * 8, 0, 0));
+            }
+        }
+        const int c0 = dd - 1; // column of row 1: the top boundary row is read there (used by lane 0 only)
+        const double *pt = DIR > 0 ? sx + c0 : sx + c0 - (PF - 1);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) q.top[u] = pt[DIR > 0 ? u : PF - 1 - u];
+    };
+    auto compute = [&](const Chunk &q, int t) {
+        const int dd = d0 + DIR * t;
+        double *pw[RPL];
+        unsigned cm[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            const int cb = dd - j[k];
+            pw[k] = DIR > 0 ? srow[k] + cb : srow[k] + cb - (PF - 1);
+            cm[k] = (unsigned)(cb - 1);
+        }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int d = dc + DIR * u;
+            double above[RPL], below[RPL];
+            const int w = DIR > 0 ? u : PF - 1 - u;
+            // the row above the lane's first row lives in the previous lane; lane 0 has no previous
+            // lane and keeps the fallback operand: the top boundary row
+            {
+                const double src = DIR > 0 ? lat[RPL - 1] : q.ah[RPL - 1][u];
+                const int lo = __builtin_amdgcn_update_dpp(__double2loint(q.top[u]), __double2loint(src), 0x138, 0xf, 0xf, false);
+                const int hi = __builtin_amdgcn_update_dpp(__double2hiint(q.top[u]), __double2hiint(src), 0x138, 0xf, 0xf, false);
+                above[0] = __hiloint2double(hi, lo);
+            }
+            {
+                const double src = DIR > 0 ? q.ah[0][u] : lat[0];
+                const int lo = __builtin_amdgcn_mov_dpp(__double2loint(src), 0x130, 0xf, 0xf, true);
+                const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(src), 0x130, 0xf, 0xf, true);
+                below[RPL - 1] = __hiloint2double(hi, lo); // lane 63's last row is never interior
+            }
+#pragma unroll
+            for (int k = 1; k < RPL; ++k) {
+                above[k] = DIR > 0 ? lat[k - 1] : q.ah[k - 1][u];
+                below[k - 1] = DIR > 0 ? q.ah[k][u] : lat[k];
+            }
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
-                const int c = d - j[k];
-                int ca = c + DIR, cb = c;
-                ca = ca < 0 ? 0 : (ca > nx - 1 ? nx - 1 : ca);
-                cb = cb < 0 ? 0 : (cb > nx - 1 ? nx - 1 : cb);
-                qa[k][u] = srow[k][ca];
-                qb[k][u] = brow[k][cb];
+                const unsigned cc = DIR > 0 ? cm[k] + (unsigned)u : cm[k] - (unsigned)u; // column - 1
+                const bool act = inter[k] && cc < (unsigned)(nx - 2);
+                const double ahead = q.ah[k][u];
+                const double E = DIR > 0 ? ahead : lat[k];
+                const double W = DIR > 0 ? lat[k] : ahead;
+                double v = alpha * self[k] + beta * (E + W + below[k] + above[k] - h2 * q.bv[k][u]);
+                v = act ? v : self[k];
+                double *dst = act ? pw[k] : dummy;
+                dst[w] = v;
+                lat[k] = v;
+                self[k] = ahead;
             }
-            int c0 = d - 1;
-            c0 = c0 < 0 ? 0 : (c0 > nx - 1 ? nx - 1 : c0);
-            qt[u] = sx[c0];
         }
     };
-    fetch(aq, bq, tq, d0);
-    for (int t0 = 0; t0 < nsteps; t0 += PF) {
-        fetch(an, bn, tn, d0 + DIR * (t0 + PF)); // used PF .. 2*PF-1 steps from now
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int d = d0 + DIR * (t0 + u); // steps past the last one update nothing: no row is in range
-            double ahead[RPL], bv[RPL], above[RPL], below[RPL];
-#pragma unroll
-            for (int k = 0; k < RPL; ++k) ahead[k] = aq[k][u], bv[k] = bq[k][u];
-            const double top = tq[u];
-            if (DIR > 0) {
-                const double p = wave_from_prev(lat[RPL - 1]);
-                above[0] = lane == 0 ? top : p;
-                below[RPL - 1] = wave_from_next(ahead[0]);
-#pragma unroll
-                for (int k = 1; k < RPL; ++k) above[k] = lat[k - 1], below[k - 1] = ahead[k];
-            } else {
-                const double p = wave_from_prev(ahead[RPL - 1]);
-                above[0] = lane == 0 ? top : p;
-                below[RPL - 1] = wave_from_next(lat[0]);
-#pragma unroll
-                for (int k = 1; k < RPL; ++k) above[k] = ahead[k - 1], below[k - 1] = lat[k];
-            }
-#pragma unroll
-            for (int k = 0; k < RPL; ++k) {
-                const int c = d - j[k];
-                const bool inr = strm[k] && c >= clo && c <= chi;
-                const bool act = inter[k] && c >= 1 && c <= nx - 2;
-                const double E = DIR > 0 ? ahead[k] : lat[k];
-                const double W = DIR > 0 ? lat[k] : ahead[k];
-                double v = alpha * self[k] + beta * (E + W + below[k] + above[k] - h2 * bv[k]);
-                v = act ? v : self[k];
-                if (act) srow[k][c] = v;
-                lat[k] = inr ? v : lat[k];
-                self[k] = inr ? ahead[k] : self[k];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            tq[u] = tn[u];
-#pragma unroll
-            for (int k = 0; k < RPL; ++k) aq[k][u] = an[k][u], bq[k][u] = bn[k][u];
-        }
+    Chunk A, B;
+    fetch(A, 0);
+    for (int t = 0; t < nsteps; t += 2 * PF) {
+        fetch(B, t + PF);
+        compute(A, t);
+        fetch(A, t + 2 * PF);
+        compute(B, t + PF);
     }
 }
 
 template <int RPL>
 __global__ __launch_bounds__(256) void mg_sor_wave_kernel(const double *__restrict__ b, double *x,
-                                                          double *__restrict__ r, int ny, int nx, i64 ld, int ldl,
+                                                          double *__restrict__ r, int ny, int nx, int ld, int ldl,
                                                           double h2, int iterations, int backward, i64 bstride)
 {
-    extern __shared__ double sx[];
+    extern __shared__ double smem[];
+    double *const sx = smem + SORW_GUARD;           // the grid; guard zones on both sides
+    double *const dummy = sx + ny * ldl + (threadIdx.x & 63); // inactive cells write here (inside the back guard)
     b += (i64)blockIdx.x * bstride;
     x += (i64)blockIdx.x * bstride;
     if (r) r += (i64)blockIdx.x * bstride;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int j = wv; j < ny; j += 4)
-        for (int i = lane; i < nx; i += 64) sx[j * ldl + i] = x[j * ld + i];
+        for (int i = lane; i < nx; i += 64) sx[j * ldl + i] = x[(i64)j * ld + i];
+    if (tid < SORW_GUARD) smem[tid] = 0.0;
+    if (tid < SORW_GUARD_BACK) sx[ny * ldl + tid] = 0.0;
     __syncthreads();
     if (wv == 0) {
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)b, 0, ny * ld * 8, 0x00020000);
         for (int it = 0; it < iterations; ++it) {
-            sor_wave_sweep<RPL, 1>(b, sx, ny, nx, ld, ldl, h2, lane);
-            if (backward) sor_wave_sweep<RPL, -1>(b, sx, ny, nx, ld, ldl, h2, lane);
+            sor_wave_sweep<RPL, 1>(brs, sx, dummy, ny, nx, ld, ldl, h2, lane);
+            if (backward) sor_wave_sweep<RPL, -1>(brs, sx, dummy, ny, nx, ld, ldl, h2, lane);
         }
     }
     __syncthreads();
@@ -269,11 +297,11 @@ __global__ __launch_bounds__(256) void mg_sor_wave_kernel(const double *__restri
     for (int j = wv; j < ny; j += 4)
         for (int i = lane; i < nx; i += 64) {
             const double c = sx[j * ldl + i];
-            x[j * ld + i] = c;
+            x[(i64)j * ld + i] = c;
             if (r && j >= 1 && j <= ny - 2 && i >= 1 && i <= nx - 2) {
                 const double left = sx[j * ldl + i - 1] * hh, cent = c * hh;
-                r[j * ld + i] = b[j * ld + i] - left -
-                                (sx[j * ldl + i + 1] + sx[(j - 1) * ldl + i] + sx[(j + 1) * ldl + i]) * hh + cent * 4;
+                r[(i64)j * ld + i] = b[(i64)j * ld + i] - left -
+                                     (sx[j * ldl + i + 1] + sx[(j - 1) * ldl + i] + sx[(j + 1) * ldl + i]) * hh + cent * 4;
             }
         }
 }
@@ -313,12 +341,12 @@ extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64
         const bool lds = ny * (i64)ldl <= MG_SOR_LDS_DOUBLES;
         int nt = (int)(((ny - 2) + 63) / 64 * 64);
         if (nt > 1024) nt = 1024;
-        // measured: ahead of the one-thread-per-row kernel only with one row per lane and few grids in flight
-        if (lds && ny - 1 <= 64 * 4 && (g_sor_single_wave == 2 || (g_sor_single_wave == 1 && ny - 1 <= 64 && nbatch <= 256))) {
-            const size_t bytes = (size_t)ny * ldl * sizeof(double);
+        // measured 1.6-2.6x ahead of the one-thread-per-row kernel with one or two rows per lane
+        if (lds && ny - 1 <= 64 * 4 && ny * ld < ((i64)1 << 27) && (g_sor_single_wave == 2 || (g_sor_single_wave == 1 && ny - 1 <= 128))) {
+            const size_t bytes = ((size_t)ny * ldl + SORW_GUARD + SORW_GUARD_BACK) * sizeof(double);
             static bool wattr_set = false;
             if (!wattr_set) {
-                const int cap = MG_SOR_LDS_DOUBLES * (int)sizeof(double);
+                const int cap = (MG_SOR_LDS_DOUBLES + SORW_GUARD + SORW_GUARD_BACK) * (int)sizeof(double);
                 MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -326,13 +354,13 @@ extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64
             }
             const dim3 grid((unsigned)nbatch), block(256);
             if (ny - 1 <= 64)
-                hipLaunchKernelGGL(mg_sor_wave_kernel<1>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, ld, ldl, h2,
+                hipLaunchKernelGGL(mg_sor_wave_kernel<1>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, (int)ld, ldl, h2,
                                    (int)iterations, backward, bstride);
             else if (ny - 1 <= 128)
-                hipLaunchKernelGGL(mg_sor_wave_kernel<2>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, ld, ldl, h2,
+                hipLaunchKernelGGL(mg_sor_wave_kernel<2>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, (int)ld, ldl, h2,
                                    (int)iterations, backward, bstride);
             else
-                hipLaunchKernelGGL(mg_sor_wave_kernel<4>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, ld, ldl, h2,
+                hipLaunchKernelGGL(mg_sor_wave_kernel<4>, grid, block, bytes, st, b, x, r, (int)ny, (int)nx, (int)ld, ldl, h2,
                                    (int)iterations, backward, bstride);
             MG_LAUNCH_CHECK("mg_sor (single-wave wavefront)");
             return 0;
