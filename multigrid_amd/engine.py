@@ -260,14 +260,14 @@ class SlabMultigrid:
             self._restrict(l)
         return src
 
-    def _smooth_level0(self, n, want_norm, crs=None):
+    def _smooth_level0(self, n, want_norm, crs=None, store_r=False):
         xs = [self._xa[0], self._xb[0]]
         if not self._b0_halo_valid:  # b0 only changes when the caller sets it
             if self.fused and self.world > 1:
                 self._exchange([(self.b[0], self.plan.levels[0], self.plan.halo - 1)])
             self._b0_halo_valid = True
         # the residual of the finest level is restricted right away: b_1 is ready for the next descent
-        store_r = self.store_residual_every_cycle or not self.fused
+        store_r = store_r or self.store_residual_every_cycle or not self.fused
         res = self._smooth(0, xs[self._cur0], crs, n, self.r[0] if store_r else None, self.norm if want_norm else None,
                            finest=True, crs_has_halo=self.n_para == 1, restrict=True)
         self._r0_stale = not store_r
@@ -351,8 +351,10 @@ class SlabMultigrid:
             self._tail_graph = self.ops.graph_end()
         self.ops.graph_launch(self._tail_graph)
 
-    def _cycle(self):
-        """One V-cycle (the body of the loop at parallel_multigrid.py:270-347), norm included."""
+    def _cycle(self, store_r=False):
+        """One V-cycle (the body of the loop at parallel_multigrid.py:270-347), norm included.
+        store_r: the finest pass also writes the residual array (a caller that knows this is its
+        last cycle saves the separate residual launch that way)."""
         n_para = self.n_para
         # ---- descent (b_1 was produced together with the finest residual, by presmooth or the last cycle)
         for l in range(1, n_para):
@@ -364,23 +366,38 @@ class SlabMultigrid:
             # x_l of the descent is in _xa[l] (a from-zero pass always writes there)
             corr = self._smooth(l, self._xa[l], corr, self.N2, self.r[l] if self.keep_ascent_residuals else None,
                                 crs_has_halo=l == n_para - 1)
-        self._smooth_level0(self.N2, want_norm=True, crs=corr)
+        self._smooth_level0(self.N2, want_norm=True, crs=corr, store_r=store_r)
 
     # ------------------------------------------------------------------ drivers
-    def _run_cycle(self):
+    def _run_cycle(self, store_r=False):
+        store_r = bool(store_r) and self.fused and not self.store_residual_every_cycle
         if self.use_graph and self.world == 1:
-            # one graph per array the finest x starts the cycle in; a cycle may leave it in the other
-            key = self._cur0
+            # one graph per array the finest x starts the cycle in (a cycle may leave it in the other)
+            # and per residual-store variant
+            key = (self._cur0, store_r)
             if key not in self._graphs:
-                self.ops.graph_begin()
-                self._cycle()
-                self._graphs[key] = (self.ops.graph_end(), self._cur0)
-                self._cur0 = key
+                self._capture_graphs()
             g, end = self._graphs[key]
             self.ops.graph_launch(g)
             self._cur0 = end
+            self._r0_stale = not (store_r or self.store_residual_every_cycle or not self.fused)
         else:
-            self._cycle()
+            self._cycle(store_r)
+
+    def _capture_graphs(self):
+        """Capture every variant of the cycle (capturing records, it does not execute): later cycles
+        then never pay for a capture, whichever array the finest x is in."""
+        cur, stale = self._cur0, self._r0_stale
+        variants = [False] if (self.store_residual_every_cycle or not self.fused) else [False, True]
+        for start in (0, 1):
+            for store_r in variants:
+                if (start, store_r) in self._graphs:
+                    continue
+                self._cur0 = start
+                self.ops.graph_begin()
+                self._cycle(store_r)
+                self._graphs[(start, store_r)] = (self.ops.graph_end(), self._cur0)
+        self._cur0, self._r0_stale = cur, stale
 
     def _global_err(self):
         if self.world == 1:
@@ -398,8 +415,8 @@ class SlabMultigrid:
         """Run exactly k V-cycles (no stop test); returns max|r| after each."""
         errs = []
         self.ops.begin()
-        for _ in range(k):
-            self._run_cycle()
+        for c in range(k):
+            self._run_cycle(store_r=c == k - 1)  # the last pass leaves the residual array current
             errs.append(self._global_err())
         self.ops.end()
         self.materialize_residual()
