@@ -286,7 +286,12 @@ class SlabMultigrid:
         o.zero_(self._xw0_pad)
         o.sor(self.bw[0], self.xw[0], self.rw[0], W[0].nx, W[0].h, self.N1, self.coarse_ordering)
         if self.eager_dead_levels:
-            self._tail_below()
+            if self.world == 1 and not self.fix_coarse_ascent:
+                # nothing in the cycle reads what these levels produce: they run beside the ascent
+                with o.side():
+                    self._tail_below()
+            else:
+                self._tail_below()
 
     def _tail_below(self):
         """The whole-domain levels below the first (parallel_multigrid.py:294-304)."""
@@ -367,6 +372,7 @@ class SlabMultigrid:
             corr = self._smooth(l, self._xa[l], corr, self.N2, self.r[l] if self.keep_ascent_residuals else None,
                                 crs_has_halo=l == n_para - 1)
         self._smooth_level0(self.N2, want_norm=True, crs=corr, store_r=store_r)
+        self.ops.join_side()
 
     # ------------------------------------------------------------------ drivers
     def _run_cycle(self, store_r=False):

@@ -4,6 +4,7 @@
 the logical column count, and enqueues one call of the C ABI (include/mg_hip.h) on `stream`.
 The engine only ever talks to an object with this interface.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -22,6 +23,7 @@ class HipOps:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         # a stream of its own: the null stream cannot be captured into a hipGraph
         self.stream = torch.cuda.Stream(self.device)
+        self._side, self._on_side, self._side_pending = None, False, False
 
     # ---- memory / stream plumbing (torch) -------------------------------------------------
     def zeros(self, rows, ld):
@@ -32,7 +34,32 @@ class HipOps:
 
     @property
     def _s(self):
-        return self.stream.cuda_stream
+        return (self._side if self._on_side else self.stream).cuda_stream
+
+    # Work that nothing later in the cycle reads can run beside the main sequence: side() routes the
+    # calls made inside it to a second stream that starts after everything enqueued so far, and
+    # join_side() makes the main stream wait for it.  Both are event record/wait pairs, so they
+    # also work while the main stream is being captured into a graph (the side stream joins the capture
+    # and must be joined back before the capture ends).
+    @contextlib.contextmanager
+    def side(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self._side.wait_event(ev)
+        self._on_side, self._side_pending = True, True
+        try:
+            yield
+        finally:
+            self._on_side = False
+
+    def join_side(self):
+        if self._side_pending:
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self.stream.wait_event(ev)
+            self._side_pending = False
 
     def ctx(self):
         """Context in which torch ops and torch.distributed calls are ordered with the kernels."""
