@@ -109,6 +109,7 @@ class SlabMultigrid:
             self._corr = z(S.ny, S.ld)
         self._graphs = {}
         self._tail_graph = None
+        self._dead_graph = None
         self._b0_halo_valid = False
         self._r0_stale = False
         # store the finest residual in every cycle's pass instead of once at the end of solve()/cycles()
@@ -285,11 +286,23 @@ class SlabMultigrid:
         nw = len(W)
         o.zero_(self._xw0_pad)
         o.sor(self.bw[0], self.xw[0], self.rw[0], W[0].nx, W[0].h, self.N1, self.coarse_ordering)
-        if self.eager_dead_levels:
-            if self.world == 1 and not self.fix_coarse_ascent:
-                # nothing in the cycle reads what these levels produce: they run beside the ascent
-                with o.side():
+        if self.fix_coarse_ascent:  # then the lower levels do feed xw[0]
+            self._tail_below()
+
+    def _dead_levels(self):
+        """With the reference's loop bounds nothing in the cycle reads what the whole-domain levels
+        below the first produce.  When they are computed every cycle they run beside the rest of
+        the cycle, on the side stream; the cycle joins it at its end."""
+        if not self.eager_dead_levels or self.fix_coarse_ascent or len(self.plan.whole) < 2:
+            return
+        o = self.ops
+        with o.side():
+            if self.use_graph and self.world > 1:
+                if self._dead_graph is None:
+                    o.graph_begin()
                     self._tail_below()
+                    self._dead_graph = o.graph_end()
+                o.graph_launch(self._dead_graph)
             else:
                 self._tail_below()
 
@@ -324,6 +337,7 @@ class SlabMultigrid:
         S, H = P.levels[self.n_para], P.halo
         if self.world == 1:
             self._run_tail()
+            self._dead_levels()
             return self._xw0_pad
         stage = self.b[self.n_para]
         R = S.rows
@@ -339,6 +353,7 @@ class SlabMultigrid:
                 # rank p gets global rows p*R-H .. (p+1)*R+H-1 = padded rows p*R .. p*R+R+2H-1
                 win = self._xw0_pad.as_strided((self.world, S.ny, S.ld), (R * S.ld, S.ld, 1))
                 self._scatter_buf.view(self.world, S.ny, S.ld).copy_(win)
+            self._dead_levels()  # rank 0 only, beside the scatter and the ascent
             parts = list(self._scatter_buf.view(self.world, S.ny, S.ld).unbind(0))
             self.comm.scatter0(self._corr, parts)
         else:
@@ -461,9 +476,10 @@ class SlabMultigrid:
         for g, _ in self._graphs.values():
             self.ops.graph_destroy(g)
         self._graphs = {}
-        if self._tail_graph is not None:
-            self.ops.graph_destroy(self._tail_graph)
-            self._tail_graph = None
+        for name in ("_tail_graph", "_dead_graph"):
+            if getattr(self, name, None) is not None:
+                self.ops.graph_destroy(getattr(self, name))
+                setattr(self, name, None)
 
     def __del__(self):
         try:

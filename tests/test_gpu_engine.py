@@ -68,6 +68,27 @@ def test_engine_equals_global_oracle(gny, gnx, n_para, ordering, graph):
     eng.close()
 
 
+@pytest.mark.parametrize("gny,gnx,n_para", [(129, 129, 3), (1025, 1025, 4), (513, 2049, 5)], ids=str)
+@pytest.mark.parametrize("graph", [True, False])
+def test_dead_levels_every_cycle_on_the_side_stream(gny, gnx, n_para, graph):
+    """eager_dead_levels: the whole-domain levels below the first run every cycle, beside the ascent on a
+    second stream (inside the captured graph too); every array equals the oracle's."""
+    b = _rhs(gny, gnx, 5)
+    h = 0.37
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0, "lexicographic")
+    ref.b[:] = b
+    ref.solve(ncycles=3)
+    eng = _make(gny, gnx, n_para, h, 0.0, b, use_graph=graph, eager_dead_levels=True)
+    eng.presmooth()
+    assert eng.cycles(3) == ref.err_hist.tolist()
+    assert np.array_equal(_rows(eng, eng.x0), ref.x)
+    assert np.array_equal(_rows(eng, eng.r0), ref.r)
+    eng.ops.synchronize()
+    for k, W in enumerate(eng.plan.whole):
+        assert np.array_equal(eng.xw[k].cpu().numpy()[:, : W.nx], ref.array("xw", k))
+    eng.close()
+
+
 def test_fix_coarse_ascent_equals_oracle():
     gny = gnx = 257
     b = _rhs(gny, gnx, 3)

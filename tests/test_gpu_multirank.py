@@ -29,7 +29,8 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from multigrid_amd.engine import SlabMultigrid
-        eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank, fused=fused)
+        # dead whole-domain levels every cycle for the larger grids: rank 0 runs them as a graph on a side stream
+        eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank, fused=fused, eager_dead_levels=gny > 300)
         assert eng.comm.staged
         R = eng.plan.levels[0].rows
         a, e = eng.owned_rows()
