@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--lazy-dead-levels", action="store_true",
                     help="do not run the whole-domain levels whose result the reference schedule never uses")
     ap.add_argument("--no-fused", action="store_true", help="one kernel per operation instead of fused passes")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="B > 0: B independent (2**(n+1)+1)^2 problems advance together on one GPU "
+                         "(e.g. --batch 1024 --exp 7 --jacobi-levels 4); not the headline workload")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages messages through the host: lets several ranks share one GPU (rehearsal only)")
     return ap.parse_args()
@@ -78,15 +81,15 @@ def fill_rhs(eng, torch, n, rank):
         for xv, yv in zip(xr, yr):
             acc += sign * 50.0 * torch.exp(-7.0 * ((X.unsqueeze(0) - xv) ** 2 + (Y - yv) ** 2))
             sign = -sign
-        eng.b0[t:t2, :gnx] = acc
+        eng.b0[..., t:t2, :gnx] = acc
     # Dirichlet boundary cells carry no equation
-    eng.b0[:, 0] = 0
-    eng.b0[:, gnx - 1] = 0
+    eng.b0[..., 0] = 0
+    eng.b0[..., gnx - 1] = 0
     L0 = P.levels[0]
     if rank == 0:
-        eng.b0[L0.own0, :] = 0
+        eng.b0[..., L0.own0, :] = 0
     if rank == eng.world - 1:
-        eng.b0[L0.own1 - 1, :] = 0
+        eng.b0[..., L0.own1 - 1, :] = 0
     eng.set_b_rows(eng.local_rows(eng.b0))  # marks the halo of b as stale
     return h
 
@@ -148,7 +151,8 @@ def main():
     h = 20.0 / 2 ** (n + 1)
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
                         use_graph=not args.no_graph, fused=not args.no_fused,
-                        eager_dead_levels=not args.lazy_dead_levels)
+                        eager_dead_levels=not args.lazy_dead_levels, batch=args.batch or None)
+    nprob = args.batch or 1
     fill_rhs(eng, torch, n, rank)
     torch.cuda.synchronize()
 
@@ -177,7 +181,7 @@ def main():
     ops = eng.ops
     xs = [eng._xa[0], eng._xb[0]]
     iters = args.roofline_iters
-    pts_launch = (L0.t1 - L0.t0) * (L0.nx - 2)
+    pts_launch = (L0.t1 - L0.t0) * (L0.nx - 2) * (args.batch or 1)
 
     def timed(fn):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -210,27 +214,30 @@ def main():
         alg_bpp = 18 + 6 * 24 + 24 + 10  # per-operation compulsory bytes x the operations this launch performs
         own_bpp = 8 + 2 + 8 + 8 + 2      # what the pass itself must move: R x, R coarse x, R b, W x, W coarse b
         tkey = "fused_finest_bytes_per_launch"
+    else:
+        dom_name, dom_ms, alg_bpp, own_bpp, tkey = single["kernel"], sweep_ms, 24, 24, "jacobi_finest_bytes_per_launch"
     alg_bytes_launch = alg_bpp * pts_launch
     achieved = alg_bytes_launch / (dom_ms * 1e-3) / 1e9
 
     if rank == 0:
-        unknowns = (gny - 2) * (gnx - 2)
+        unknowns = (gny - 2) * (gnx - 2) * nprob
         ms = 1e3 * dt / args.steps
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and n == 14 and not args.batch:  # measured at 32769 x 32769
             try:
                 traffic = json.load(open(tpath)).get(tkey)
             except Exception:
                 traffic = None
-        bcyc = algorithmic_bytes_per_cycle(eng.plan)
+        bcyc = algorithmic_bytes_per_cycle(eng.plan) * nprob
         out = {
             "metric": "unknowns*V-cycles/s", "value": unknowns * args.steps / dt, "unit": "unknowns*V-cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"{gny}x{gnx} fp64 Poisson V-cycle ({gnx}x{gnx} per GPU), test.py 8-vortex RHS",
-                "n": n, "n_para": n_para, "grid": [gny, gnx], "unknowns": unknowns,
+                "workload": (f"{gny}x{gnx} fp64 Poisson V-cycle ({gnx}x{gnx} per GPU), test.py 8-vortex RHS" if not args.batch
+                             else f"{args.batch} independent {gny}x{gnx} fp64 Poisson V-cycles in one batch, test.py 8-vortex RHS"),
+                "n": n, "n_para": n_para, "grid": [gny, gnx], "batch": args.batch or None, "unknowns": unknowns,
                 "coarse_ordering": args.ordering, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
                 "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph), "fused_passes": bool(eng.fused),
                 "halo_rows": eng.plan.halo,
@@ -252,7 +259,7 @@ def main():
                 "max_abs_r_after_last_cycle": errs[-1] if errs else None,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.batch:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the GPU numbers stand on their own

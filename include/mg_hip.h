@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 1
+#define MG_ABI_VERSION 2
 
 /* flags for the stencil entry points */
 #define MG_FLAG_FINEST 1 /* launch the instantiation named "...finest..." (profiler attribution only) */
@@ -131,11 +131,13 @@ int mg_prolong_add(const double *crs, int64_t cny, int64_t cnx, int64_t cld, dou
  * mg_jacobi and mg_residual calls (smooth_parallel, core/parallel_multigrid.py:100-114, with the
  * preceding interpolate_add_to, :309/:322), but x and b are read once and x written once.
  * Needs 16-byte aligned arrays with an even ld.
+  * Batches: nbatch grids, bstride elements apart in b/x_in/x_out/r (even), cstride in crs (and cbstride in
+ * coarse_b below); one set of norm slots accumulates the max over all grids.
  */
 int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
                     int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld, int64_t j0,
                     int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps, double h,
-                    uint64_t *norm_slots, void *stream);
+                    uint64_t *norm_slots, int64_t nbatch, int64_t bstride, int64_t cstride, void *stream);
 /*
  * mg_smooth_fused with the full-weighting restriction of the residual fused in as a last stage:
  * coarse rows T0 <= T < T1 of coarse_b (cbny x cbnx, interior columns) are written as mg_restrict
@@ -149,7 +151,8 @@ int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out,
                              int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld,
                              int64_t j0, int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps,
                              double h, uint64_t *norm_slots, double *coarse_b, int64_t cbny, int64_t cbnx,
-                             int64_t cbld, int64_t T0, int64_t T1, void *stream);
+                             int64_t cbld, int64_t T0, int64_t T1, int64_t nbatch, int64_t bstride,
+                             int64_t cstride, int64_t cbstride, void *stream);
 /* Tuning knobs of mg_smooth_fused: column pairs per lane (1 or 2), rows per tile (0 = automatic). */
 int mg_set_fused_tuning(int unroll, int rows);
 

@@ -39,6 +39,7 @@ struct FusedArgs {
     u64 *norm;
     double *cb;          // coarse right-hand side produced by the fused restriction (RESTRICT)
     i64 cbnx, cbld, T0, T1; // its columns, leading dimension, and the coarse rows to produce
+    i64 nbatch, bstride, cstride, cbstride; // number of grids; elements between consecutive grids of a batch: fine arrays, crs, cb
 };
 
 __device__ __forceinline__ double lane_bcast(double v, int src)
@@ -75,8 +76,17 @@ using int_c = std::integral_constant<int, N>;
 //    a PLAIN instantiation without any of the per-cell selects;
 //  * row indices are 32-bit, so the uniform row tests are scalar compares.
 template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
-__global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a)
+__global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
 {
+    FusedArgs a = a0; // blockIdx.y = grid of the batch
+    {
+        const i64 g = blockIdx.y;
+        a.b += g * a.bstride, a.xout += g * a.bstride;
+        if (a.xin) a.xin += g * a.bstride;
+        if (a.r) a.r += g * a.bstride;
+        if (a.crs) a.crs += g * a.cstride;
+        if (a.cb) a.cb += g * a.cbstride;
+    }
     static_assert(!RESTRICT || RESID, "the restriction consumes the residual stage");
     constexpr int D = K + (RESID ? 1 : 0);   // pipeline stages that hold a three-row window
     constexpr int DC = D + (RESTRICT ? 1 : 0); // dependency depth: what validity shrinks by
@@ -487,12 +497,12 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     int rpb = g_fused_rows;
     if (rpb <= 0) {
         rpb = 64; // measured at 32769 x 32769: 64-row tiles are as fast as or faster than taller ones at every depth
-        while (rpb > 8 * D && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) < 2048) rpb >>= 1;
+        while (rpb > 8 * D && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) * a.nbatch < 2048) rpb >>= 1;
     }
     a.rpb = rpb;
     a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
-    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U>), dim3((unsigned)(a.ncb * a.nrc)),
-                       dim3(256), 0, st, a);
+    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U>),
+                       dim3((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), dim3(256), 0, st, a);
     MG_LAUNCH_CHECK("mg_smooth_fused");
     return 0;
 }
@@ -527,9 +537,14 @@ static int pick_mode(const FusedArgs &a, bool prolong, bool zero, bool resid, bo
 static int smooth_fused_impl(const double *b, const double *x_in, double *x_out, double *r, const double *crs, i64 ny,
                              i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo, i64 fix_hi,
                              i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, bool want_resid, double *coarse_b,
-                             i64 cbny, i64 cbnx, i64 cbld, i64 T0, i64 T1, void *stream)
+                             i64 cbny, i64 cbnx, i64 cbld, i64 T0, i64 T1, i64 nbatch, i64 bstride, i64 cstride,
+                             i64 cbstride, void *stream)
 {
     MG_REQUIRE(b && x_out, "mg_smooth_fused: null array");
+    MG_REQUIRE(nbatch >= 1 && nbatch <= 65535, "mg_smooth_fused: nbatch %lld outside 1..65535", (long long)nbatch);
+    MG_REQUIRE(nbatch == 1 || (bstride >= ny * ld && bstride % 2 == 0 && (!crs || cstride >= cny * cld) &&
+                               (!coarse_b || cbstride >= cbny * cbld)),
+               "mg_smooth_fused: batch strides overlap consecutive grids (or the fine stride is odd)");
     MG_REQUIRE(sweeps >= 1 && sweeps <= 6, "mg_smooth_fused: 1..6 sweeps per pass, got %d", sweeps);
     MG_REQUIRE(ny >= 3 && nx >= 3 && ld >= nx, "mg_smooth_fused: bad shape");
     MG_REQUIRE(ld % 2 == 0 && mg_aligned(b, 16) && mg_aligned(x_out, 16) && (!x_in || mg_aligned(x_in, 16)) &&
@@ -572,6 +587,7 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
     a.h2 = h * h, a.hh = 1 / (h * h), a.norm = (u64 *)norm_slots;
     a.rpb = a.ncb = a.nrc = a.ntc = 0;
     a.cb = coarse_b, a.cbnx = cbnx, a.cbld = cbld, a.T0 = T0, a.T1 = T1;
+    a.nbatch = nbatch, a.bstride = bstride, a.cstride = cstride, a.cbstride = cbstride;
     const bool zero = x_in == nullptr, prolong = crs != nullptr, restr = coarse_b != nullptr;
     const bool resid = want_resid || restr;
     hipStream_t st = (hipStream_t)stream;
@@ -587,19 +603,21 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
 
 extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
                                i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo,
-                               i64 fix_hi, i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, void *stream)
+                               i64 fix_hi, i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, i64 nbatch,
+                               i64 bstride, i64 cstride, void *stream)
 {
     return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
-                             h, norm_slots, r != nullptr, nullptr, 0, 0, 0, 0, 0, stream);
+                             h, norm_slots, r != nullptr, nullptr, 0, 0, 0, 0, 0, nbatch, bstride, cstride, 0, stream);
 }
 
 extern "C" int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out, double *r,
                                         const double *crs, i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0,
                                         i64 j1, i64 fix_lo, i64 fix_hi, i64 ofst_j, int sweeps, double h,
                                         uint64_t *norm_slots, double *coarse_b, i64 cbny, i64 cbnx, i64 cbld, i64 T0,
-                                        i64 T1, void *stream)
+                                        i64 T1, i64 nbatch, i64 bstride, i64 cstride, i64 cbstride, void *stream)
 {
     MG_REQUIRE(coarse_b, "mg_smooth_fused_restrict: null coarse array");
     return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
-                             h, norm_slots, true, coarse_b, cbny, cbnx, cbld, T0, T1, stream);
+                             h, norm_slots, true, coarse_b, cbny, cbnx, cbld, T0, T1, nbatch, bstride, cstride,
+                             cbstride, stream);
 }

@@ -41,7 +41,7 @@ class SlabMultigrid:
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
-                 store_residual_every_cycle=False):
+                 store_residual_every_cycle=False, batch=None):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -73,7 +73,13 @@ class SlabMultigrid:
 
         P = self.plan
         H = P.halo
-        z = ops.zeros
+        # batch = B: B independent (gny x gnx) problems advance together, every level array gets a
+        # leading batch dimension and every launch covers all of them (one rank only).  The norm and
+        # the stop rule are taken over the whole batch.
+        if batch is not None and world != 1:
+            raise ValueError("batched solves run on one rank")
+        self.batch = batch
+        z = (lambda rows, ld: ops.zeros(rows, ld, batch)) if batch is not None else ops.zeros
         # Jacobi levels: two x arrays (ping-pong), b, r.  b has one more level (the staging level).
         self._xa = [z(L.ny, L.ld) for L in P.levels[:n_para]]
         self._xb = [z(L.ny, L.ld) for L in P.levels[:n_para]]
@@ -88,9 +94,10 @@ class SlabMultigrid:
         S, W0 = P.levels[n_para], P.whole[0]
         if world == 1:
             self._xw0_pad = z(S.ny, S.ld)
-            self.xw.append(self._xw0_pad[H : H + W0.ny])
-            self.bw.append(self.b[n_para][H : H + W0.ny])
-            self.rw.append(z(W0.ny, W0.ld))
+            self.xw.append(self._xw0_pad[..., H : H + W0.ny, :])
+            self.bw.append(self.b[n_para][..., H : H + W0.ny, :])
+            # the same window of an equally padded array: one batch stride for all arrays of a launch
+            self.rw.append(z(S.ny, S.ld)[..., H : H + W0.ny, :])
         elif rank == 0:
             self._xw0_pad = z(W0.ny + 2 * H, W0.ld)
             self.xw.append(self._xw0_pad[H : H + W0.ny])
@@ -161,17 +168,17 @@ class SlabMultigrid:
         """Set the owned rows of the finest x (both ping-pong arrays, so boundary values agree)."""
         a, e = self.owned_rows()
         for arr in (self._xa[0], self._xb[0]):
-            arr[a:e, : self.plan.gnx] = rows
+            arr[..., a:e, : self.plan.gnx] = rows
 
     def set_b_rows(self, rows):
         a, e = self.owned_rows()
-        self.b[0][a:e, : self.plan.gnx] = rows
+        self.b[0][..., a:e, : self.plan.gnx] = rows
         self._b0_halo_valid = False
 
     def local_rows(self, arr):
         """The owned rows of a finest-level array as a (rows x gnx) view."""
         a, e = self.owned_rows()
-        return arr[a:e, : self.plan.gnx]
+        return arr[..., a:e, : self.plan.gnx]
 
     # ------------------------------------------------------------------ halo exchange
     def _exchange(self, items, up=True, down=True):

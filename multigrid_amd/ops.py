@@ -26,8 +26,8 @@ class HipOps:
         self._side, self._on_side, self._side_pending = None, False, False
 
     # ---- memory / stream plumbing (torch) -------------------------------------------------
-    def zeros(self, rows, ld):
-        return torch.zeros((rows, ld), dtype=torch.float64, device=self.device)
+    def zeros(self, rows, ld, batch=None):
+        return torch.zeros((rows, ld) if batch is None else (batch, rows, ld), dtype=torch.float64, device=self.device)
 
     def norm_slots(self):
         return torch.zeros(_lib.NORM_SLOTS, dtype=torch.int64, device=self.device)
@@ -86,26 +86,53 @@ class HipOps:
         self.stream.synchronize()
 
     # ---- kernels ---------------------------------------------------------------------------
+    # Arrays are (rows x ld) tensors, or (batch x rows x ld) for a batch of independent grids: every
+    # array of a call then has the same leading batch dimension and one launch covers all grids.
+    @staticmethod
+    def _nb(t):
+        """(nbatch, batch stride, rows, ld) of a 2-D or 3-D level array"""
+        if t.dim() == 3:
+            return t.shape[0], t.stride(0), t.shape[1], t.stride(1)
+        return 1, 0, t.shape[0], t.stride(0)
+
+    @staticmethod
+    def _same_layout(*ts):
+        """the entry points with ONE batch stride and leading dimension need arrays laid out alike"""
+        ts = [t for t in ts if t is not None]
+        if any(t.stride() != ts[0].stride() or t.shape != ts[0].shape for t in ts[1:]):
+            raise _lib.MgError("arrays of one launch must share shape and strides: " +
+                               ", ".join(f"{tuple(t.shape)}/{t.stride()}" for t in ts))
+
     def jacobi(self, b, x, xo, nx, j0, j1, h, finest=False):
-        check(self.L.mg_jacobi(b.data_ptr(), x.data_ptr(), xo.data_ptr(), x.shape[0], nx, x.stride(0), j0, j1, h, 1, 0,
+        self._same_layout(b, x, xo)
+        nb, bs, ny, ld = self._nb(x)
+        check(self.L.mg_jacobi(b.data_ptr(), x.data_ptr(), xo.data_ptr(), ny, nx, ld, j0, j1, h, nb, bs,
                                _lib.FLAG_FINEST if finest else 0, self._s))
 
     def jacobi_from_zero(self, b, xo, nx, j0, j1, h, finest=False):
-        check(self.L.mg_jacobi_from_zero(b.data_ptr(), xo.data_ptr(), xo.shape[0], nx, xo.stride(0), j0, j1, h, 1, 0,
+        self._same_layout(b, xo)
+        nb, bs, ny, ld = self._nb(xo)
+        check(self.L.mg_jacobi_from_zero(b.data_ptr(), xo.data_ptr(), ny, nx, ld, j0, j1, h, nb, bs,
                                          _lib.FLAG_FINEST if finest else 0, self._s))
 
     def residual(self, r, x, b, nx, j0, j1, h, norm=None, finest=False):
-        check(self.L.mg_residual(r.data_ptr(), x.data_ptr(), b.data_ptr(), x.shape[0], nx, x.stride(0), j0, j1, h,
-                                 norm.data_ptr() if norm is not None else None, 1, 0,
+        self._same_layout(r, x, b)
+        nb, bs, ny, ld = self._nb(x)
+        check(self.L.mg_residual(r.data_ptr(), x.data_ptr(), b.data_ptr(), ny, nx, ld, j0, j1, h,
+                                 norm.data_ptr() if norm is not None else None, nb, bs,
                                  _lib.FLAG_FINEST if finest else 0, self._s))
 
     def restrict(self, f, fnx, c, cnx, J0, J1, oi, oj):
-        check(self.L.mg_restrict(f.data_ptr(), f.shape[0], fnx, f.stride(0), c.data_ptr(), c.shape[0], cnx,
-                                 c.stride(0), J0, J1, oi, oj, 1, 0, 0, self._s))
+        nb, fbs, fny, fld = self._nb(f)
+        _, cbs, cny, cld = self._nb(c)
+        check(self.L.mg_restrict(f.data_ptr(), fny, fnx, fld, c.data_ptr(), cny, cnx, cld, J0, J1, oi, oj, nb, fbs, cbs,
+                                 self._s))
 
     def prolong_add(self, c, cnx, f, fnx, t0, t1, oi, oj):
-        check(self.L.mg_prolong_add(c.data_ptr(), c.shape[0], cnx, c.stride(0), f.data_ptr(), f.shape[0], fnx,
-                                    f.stride(0), t0, t1, 1, fnx - 2, oi, oj, 1, 0, 0, self._s))
+        nb, fbs, fny, fld = self._nb(f)
+        _, cbs, cny, cld = self._nb(c)
+        check(self.L.mg_prolong_add(c.data_ptr(), cny, cnx, cld, f.data_ptr(), fny, fnx, fld, t0, t1, 1, fnx - 2, oi, oj,
+                                    nb, cbs, fbs, self._s))
 
     supports_fused = True
 
@@ -114,20 +141,24 @@ class HipOps:
         """[x_in += P(crs)] -> `sweeps` Jacobi sweeps -> [residual] -> [restriction into coarse_b];
         x_in None = start from zero."""
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        common = (p(b), p(x_in), p(x_out), p(r), p(crs), x_out.shape[0], nx, x_out.stride(0),
-                  crs.shape[0] if crs is not None else 0, cnx, crs.stride(0) if crs is not None else 0, j0, j1,
-                  fix_lo, fix_hi, oj, sweeps, h, p(norm))
+        self._same_layout(b, x_in, x_out, r)
+        nb, bs, ny, ld = self._nb(x_out)
+        _, cs, cny, cld = self._nb(crs) if crs is not None else (1, 0, 0, 0)
+        common = (p(b), p(x_in), p(x_out), p(r), p(crs), ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, oj, sweeps,
+                  h, p(norm))
         if coarse_b is None:
-            check(self.L.mg_smooth_fused(*common, self._s))
+            check(self.L.mg_smooth_fused(*common, nb, bs, cs, self._s))
         else:
-            check(self.L.mg_smooth_fused_restrict(*common, p(coarse_b), coarse_b.shape[0], cbnx, coarse_b.stride(0), T0,
-                                                  T1, self._s))
+            _, cbs, cbny, cbld = self._nb(coarse_b)
+            check(self.L.mg_smooth_fused_restrict(*common, p(coarse_b), cbny, cbnx, cbld, T0, T1, nb, bs, cs, cbs,
+                                                  self._s))
 
     def sor(self, b, x, r, nx, h, iterations, ordering):
-        check(self.L.mg_sor(b.data_ptr(), x.data_ptr(), r.data_ptr() if r is not None else None, x.shape[0], nx,
-                            x.stride(0), h, iterations, 1,
-                            {"lexicographic": _lib.SOR_LEXICOGRAPHIC, "redblack": _lib.SOR_REDBLACK}[ordering], 1, 0,
-                            self._s))
+        self._same_layout(b, x, r)
+        nb, bs, ny, ld = self._nb(x)
+        check(self.L.mg_sor(b.data_ptr(), x.data_ptr(), r.data_ptr() if r is not None else None, ny, nx, ld, h,
+                            iterations, 1, {"lexicographic": _lib.SOR_LEXICOGRAPHIC, "redblack": _lib.SOR_REDBLACK}[ordering],
+                            nb, bs, self._s))
 
     def norm_reset(self, slots):
         check(self.L.mg_norm_reset(slots.data_ptr(), self._s))

@@ -14,12 +14,25 @@ import oracle
 _SLOTS = 64
 
 
+def _batched(fn):
+    """Apply a per-grid method to every grid of a batch: tensor arguments with a leading batch dimension
+    are sliced, everything else is passed through."""
+    def wrapper(self, *args, **kw):
+        nb = max([a.shape[0] for a in list(args) + list(kw.values()) if torch.is_tensor(a) and a.dim() == 3] or [0])
+        if nb == 0:
+            return fn(self, *args, **kw)
+        pick = lambda a, k: a[k] if (torch.is_tensor(a) and a.dim() == 3) else a  # noqa: E731
+        for k in range(nb):
+            fn(self, *[pick(a, k) for a in args], **{n: pick(a, k) for n, a in kw.items()})
+    return wrapper
+
+
 class OracleOps:
     name = "oracle"
     supports_graphs = False
 
-    def zeros(self, rows, ld):
-        return torch.zeros((rows, ld), dtype=torch.float64)
+    def zeros(self, rows, ld, batch=None):
+        return torch.zeros((rows, ld) if batch is None else (batch, rows, ld), dtype=torch.float64)
 
     def norm_slots(self):
         return torch.zeros(_SLOTS, dtype=torch.int64)
@@ -49,18 +62,21 @@ class OracleOps:
         dst.copy_(src)
 
     # ------------------------------------------------------------------ kernels
+    @_batched
     def jacobi(self, b, x, xo, nx, j0, j1, h, finest=False):
         xs = np.ascontiguousarray(x.numpy()[j0 - 1 : j1 + 1, :nx])
         bs = np.ascontiguousarray(b.numpy()[j0 - 1 : j1 + 1, :nx])
         oracle.smooth_sweep_jacobi(bs, xs, xs.copy(), h)
         xo.numpy()[j0:j1, 1 : nx - 1] = xs[1:-1, 1:-1]
 
+    @_batched
     def jacobi_from_zero(self, b, xo, nx, j0, j1, h, finest=False):
         bs = np.ascontiguousarray(b.numpy()[j0 - 1 : j1 + 1, :nx])
         xs = np.zeros_like(bs)
         oracle.smooth_sweep_jacobi(bs, xs, xs.copy(), h)
         xo.numpy()[j0:j1, 1 : nx - 1] = xs[1:-1, 1:-1]
 
+    @_batched
     def residual(self, r, x, b, nx, j0, j1, h, norm=None, finest=False):
         xs = np.ascontiguousarray(x.numpy()[j0 - 1 : j1 + 1, :nx])
         bs = np.ascontiguousarray(b.numpy()[j0 - 1 : j1 + 1, :nx])
@@ -75,6 +91,7 @@ class OracleOps:
 
     # The oracle's transfer functions take the reference's row offsets 0 / -1.  A slab with an H-row
     # halo uses offset -H: the same operator on row-shifted windows of the arrays.
+    @_batched
     def restrict(self, f, fnx, c, cnx, J0, J1, oi, oj):
         o2 = 0 if oj % 2 == 0 else -1
         f0 = 2 * (J0 - 1) + oj - o2  # first fine row of the window: its local offset becomes o2
@@ -83,6 +100,7 @@ class OracleOps:
         oracle.coarse(fs, cs, oi, o2)
         c.numpy()[J0:J1, 1 : cnx - 1] = cs[1:-1, 1:-1]
 
+    @_batched
     def prolong_add(self, c, cnx, f, fnx, t0, t1, oi, oj):
         fc = np.ascontiguousarray(f.numpy()[:, :fnx])
         if oj in (0, -1):
@@ -102,6 +120,7 @@ class OracleOps:
 
     supports_fused = True
 
+    @_batched
     def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
                      coarse_b=None, cbnx=0, T0=0, T1=0):
         """The fused pass as the sequence it stands for: prolong_add, `sweeps` Jacobi sweeps, residual
@@ -124,6 +143,7 @@ class OracleOps:
             self.residual(rt, cur, b, nx, lo, hi, h, norm if r is None else None)
             self.restrict(rt, nx, coarse_b, cbnx, T0, T1, 0, oj)
 
+    @_batched
     def sor(self, b, x, r, nx, h, iterations, ordering):
         xs = np.ascontiguousarray(x.numpy()[:, :nx])
         bs = np.ascontiguousarray(b.numpy()[:, :nx])

@@ -178,3 +178,27 @@ def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused):
         assert out[k][0] == ref.err_hist.tolist()  # every rank sees the global max-norm
     assert np.array_equal(x, ref.x)
     assert np.array_equal(r, ref.r)
+
+
+def test_batch_of_problems_equals_independent_solves():
+    """batch=B: B independent problems in one engine == B separate runs of the undecomposed oracle."""
+    B, N, n_para, h = 3, 65, 2, 0.37
+    rng = np.random.default_rng(4)
+    bs = rng.standard_normal((B, N, N))
+    bs[:, 0] = bs[:, -1] = 0
+    bs[:, :, 0] = bs[:, :, -1] = 0
+    refs = []
+    for k in range(B):
+        ref = oracle.GlobalSolver(N, N, n_para, h, 0.0)
+        ref.b[:] = bs[k]
+        ref.solve(ncycles=3)
+        refs.append(ref)
+    eng = SlabMultigrid(N, N, n_para, h, 0.0, ops=OracleOps(), world=1, rank=0, batch=B)
+    eng.set_b_rows(torch.from_numpy(bs))
+    eng.presmooth()
+    errs = eng.cycles(3)
+    assert errs == [max(r.err_hist[c] for r in refs) for c in range(3)]
+    x, r = eng.local_rows(eng.x0).numpy(), eng.local_rows(eng.r0).numpy()
+    for k in range(B):
+        assert np.array_equal(x[k], refs[k].x)
+        assert np.array_equal(r[k], refs[k].r)

@@ -89,6 +89,39 @@ def test_dead_levels_every_cycle_on_the_side_stream(gny, gnx, n_para, graph):
     eng.close()
 
 
+@pytest.mark.parametrize("B,N,n_para", [(5, 65, 2), (6, 257, 4)], ids=str)
+@pytest.mark.parametrize("graph", [True, False])
+def test_batch_of_problems_equals_independent_solves(B, N, n_para, graph):
+    """batch=B (the 1024 x 257^2 configuration in small): every launch covers all problems; each problem
+    gets the result of its own undecomposed solve, bit for bit; the norm is the max over the batch."""
+    import torch
+    from multigrid_amd.engine import SlabMultigrid
+    rng = np.random.default_rng(9)
+    bs = rng.standard_normal((B, N, N))
+    bs[:, 0] = bs[:, -1] = 0
+    bs[:, :, 0] = bs[:, :, -1] = 0
+    h = 0.41
+    refs = []
+    for k in range(B):
+        ref = oracle.GlobalSolver(N, N, n_para, h, 0.0)
+        ref.b[:] = bs[k]
+        ref.solve(ncycles=3)
+        refs.append(ref)
+    eng = SlabMultigrid(N, N, n_para, h, 0.0, world=1, rank=0, batch=B, use_graph=graph, eager_dead_levels=True)
+    eng.set_b_rows(torch.from_numpy(bs).cuda())
+    eng.presmooth()
+    errs = eng.cycles(3)
+    assert errs == [max(r.err_hist[c] for r in refs) for c in range(3)]
+    x, r = _rows(eng, eng.x0), _rows(eng, eng.r0)
+    eng.ops.synchronize()
+    for k in range(B):
+        assert np.array_equal(x[k], refs[k].x)
+        assert np.array_equal(r[k], refs[k].r)
+        for lv, W in enumerate(eng.plan.whole):
+            assert np.array_equal(eng.xw[lv][k].cpu().numpy()[:, : W.nx], refs[k].array("xw", lv))
+    eng.close()
+
+
 def test_fix_coarse_ascent_equals_oracle():
     gny = gnx = 257
     b = _rhs(gny, gnx, 3)

@@ -444,7 +444,7 @@ def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unrol
     L.check(lib.mg_smooth_fused(db.data_ptr(), None if mode == "zero" else dx.data_ptr(), out.data_ptr(),
                                 rr.data_ptr() if resid else None, dc.data_ptr() if prolong else None, ny, nx, ld,
                                 cny if prolong else 0, cnx if prolong else 0, dc.stride(0) if prolong else 0, j0, j1,
-                                flo, fhi, -1, sweeps, h, slots.data_ptr() if resid else None, st))
+                                flo, fhi, -1, sweeps, h, slots.data_ptr() if resid else None, 1, 0, 0, st))
     assert np.array_equal(out.cpu().numpy(), cur.cpu().numpy())
     if resid:
         nrm = C.c_double()
@@ -470,7 +470,7 @@ def test_fused_pass_partial_rows(L):
         cur, oth = oth, cur
     out = padded(np.full((ny, nx), 5.0))
     L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), out.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, 60, 131, 0,
-                                ny - 1, 0, 3, h, None, st))
+                                ny - 1, 0, 3, h, None, 1, 0, 0, st))
     got, ref = out.cpu().numpy(), cur.cpu().numpy()
     assert np.array_equal(got[60:131], ref[60:131])
     got[60:131] = 5.0
@@ -511,14 +511,14 @@ def test_fused_restriction_equals_separate_kernels(L, shape, sweeps, mode, store
     # separate: fused smoothing + residual, then the restriction kernel
     o1, r1, cb1 = padded(x), padded(z), padded(zc)
     s1 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
-    L.check(lib.mg_smooth_fused(*args, o1.data_ptr(), r1.data_ptr(), *cargs, s1.data_ptr(), st))
+    L.check(lib.mg_smooth_fused(*args, o1.data_ptr(), r1.data_ptr(), *cargs, s1.data_ptr(), 1, 0, 0, st))
     L.check(lib.mg_restrict(r1.data_ptr(), ny, nx, ld, cb1.data_ptr(), cny, cnx, cb1.stride(0), 2, cny - 1, 0, -1, 1, 0, 0,
                             st))
     # fused
     o2, r2, cb2 = padded(x), padded(z), padded(zc)
     s2 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
     L.check(lib.mg_smooth_fused_restrict(*args, o2.data_ptr(), r2.data_ptr() if store_r else None, *cargs, s2.data_ptr(),
-                                         cb2.data_ptr(), cny, cnx, cb2.stride(0), 2, cny - 1, st))
+                                         cb2.data_ptr(), cny, cnx, cb2.stride(0), 2, cny - 1, 1, 0, 0, 0, st))
     assert np.array_equal(o2.cpu().numpy(), o1.cpu().numpy())
     assert np.array_equal(cb2.cpu().numpy(), cb1.cpu().numpy())
     n1, n2 = C.c_double(), C.c_double()
