@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--exp", dest="n", type=int, default=14, help="grid is (2**(n+1)+1) columns wide; 14 -> 32769")
-    ap.add_argument("--jacobi-levels", dest="n_para", type=int, default=8, help="number of Jacobi (slab-distributed) levels")
+    ap.add_argument("--jacobi-levels", dest="n_para", type=int, default=0,
+                    help="number of Jacobi (slab-distributed) levels; 0 = 8, or more where the first whole-domain level "
+                         "(which grows with the rank count) would not fit LDS otherwise: 9 on 2 and 4 ranks, 10 on 8")
     ap.add_argument("--ordering", default="lexicographic", choices=["lexicographic", "redblack"])
     ap.add_argument("--roofline-iters", type=int, default=20)
     ap.add_argument("--cpu-exp", dest="cpu_n", type=int, default=12, help="grid exponent of the CPU baseline sample")
@@ -145,9 +147,14 @@ def main():
     from multigrid_amd.engine import SlabMultigrid
     from multigrid_amd.levels import algorithmic_bytes_per_cycle
 
-    n, n_para = args.n, args.n_para
+    from multigrid_amd.levels import choose_n_para
+    n = args.n
     gnx = 2 ** (n + 1) + 1
     gny = world * 2 ** (n + 1) + 1
+    n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=min(8, n - 1))
+    if not n_para:
+        sys.exit(f"no admissible number of Jacobi levels for a {gny}x{gnx} grid on {world} ranks")
+    args.n_para = n_para
     h = 20.0 / 2 ** (n + 1)
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
                         use_graph=not args.no_graph, fused=not args.no_fused,

@@ -27,11 +27,13 @@ What differs from the reference is where the data lives and how it is cut:
 The engine is written against an ``ops`` object (multigrid_amd.ops.HipOps: the HIP kernels behind
 the C ABI) and a torch.distributed process group for the exchanges.
 """
+import warnings
+
 import torch
 import torch.distributed as dist
 
 from .comm import SlabComm
-from .levels import make_plan
+from .levels import make_plan, whole_level_fits_lds
 
 
 class SlabMultigrid:
@@ -55,6 +57,11 @@ class SlabMultigrid:
         if halo is None and world > 1 and not self.fused:
             halo = 2  # one exchange per sweep needs one row; 2 keeps the halo even
         self.plan = make_plan(gny, gnx, n_para, world, rank, h0, halo)
+        W0 = self.plan.whole[0]
+        if rank == 0 and coarse_ordering == "lexicographic" and not whole_level_fits_lds(W0.ny, W0.nx):
+            warnings.warn(f"the first whole-domain level ({W0.ny} x {W0.nx}) does not fit LDS: its SSOR wavefront will walk "
+                          "global memory, an order of magnitude slower per step; use more Jacobi levels "
+                          "(levels.choose_n_para) or coarse_ordering='redblack'")
         self.comm = SlabComm(ops, group, world, rank)
         self.n_para = n_para
         self.epsilon = epsilon

@@ -163,3 +163,28 @@ def algorithmic_bytes_per_cycle(plan, keep_ascent_residuals=False, fused_zero_sw
             per = first + 2 * 24 + 24 + 10 + 18 + 6 * 24 + (24 if keep_ascent_residuals else 0)
         total += per * pts
     return total
+
+
+SOR_LDS_DOUBLES = 20000  # MG_SOR_LDS_DOUBLES of include/mg_hip.h
+
+
+def whole_level_fits_lds(ny, nx):
+    """True when the lexicographic SSOR of a (ny x nx) whole-domain level runs LDS-resident (the
+    kernels that take ~0.1-0.2 us per wavefront step); beyond that it walks global memory, an
+    order of magnitude slower per step."""
+    return ny * ((nx + 1) & ~1) <= SOR_LDS_DOUBLES
+
+
+def choose_n_para(gny, gnx, world=1, at_least=1):
+    """Smallest number of Jacobi levels >= at_least that make_plan accepts for this grid and rank
+    count and whose first whole-domain level fits LDS.  On a grid that grows with the rank count
+    (weak scaling over rows) that level grows too, so more ranks want more Jacobi levels."""
+    n_para = at_least
+    while True:
+        try:
+            plan = make_plan(gny, gnx, n_para, world, 0)
+        except ValueError:
+            return None
+        if whole_level_fits_lds(plan.whole[0].ny, plan.whole[0].nx):
+            return n_para
+        n_para += 1
