@@ -10,8 +10,9 @@ convergence value read back by the host) on a right-hand side that is already re
 Workload: the configuration BASELINE.json's metric is quoted on -- a 32769 x 32769 float64 grid
 (n = 14, ~1.07e9 unknowns, 46 GB of level arrays) per GPU.  With N > 1 ranks (one process per GPU,
 launched by torch.distributed.run) every rank keeps that slab and the global grid grows to
-(N * 32768 + 1) x 32769 rows x columns: weak scaling.  The halo rows travel by RCCL send/recv, the
-whole-domain levels are gathered onto rank 0.
+(N * 32768 + 1) x 32769 rows x columns: weak scaling.  The halo rows of the distributed levels travel by
+RCCL send/recv; the levels with fewer than 256 rows per rank are all-gathered once per cycle and computed
+redundantly on every rank.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel (the finest level's fused pass: prolongation, 6 Jacobi sweeps,
@@ -247,7 +248,7 @@ def main():
                 "n": n, "n_para": n_para, "grid": [gny, gnx], "batch": args.batch or None, "unknowns": unknowns,
                 "coarse_ordering": args.ordering, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
                 "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph), "fused_passes": bool(eng.fused),
-                "halo_rows": eng.plan.halo,
+                "halo_rows": eng.plan.halo, "distributed_levels": eng.n_dist if world > 1 else None,
                 "dead_whole_domain_levels": "computed every cycle" if eng.eager_dead_levels else "on demand", "backend": args.backend if world > 1 else None,
             },
             "roofline": {

@@ -1,8 +1,7 @@
 """Rank-to-rank data movement of the slab engine over torch.distributed.
 
-`SlabComm` wraps the four patterns the V-cycle needs -- neighbour row exchange, gather of the
-staging level to rank 0, scatter of the correction, max-reduction of the residual norm -- for two
-situations:
+`SlabComm` wraps the three patterns the V-cycle needs -- neighbour row exchange, all-gather of the
+first replicated level's right-hand side, max-reduction of the residual norm -- for two situations:
 
 * direct: the tensors can be handed to the backend as they are (CUDA tensors on `nccl`, which is
   RCCL on ROCm and moves the rows over xGMI; or CPU tensors on `gloo` in the host-only tests);
@@ -18,6 +17,7 @@ class SlabComm:
     def __init__(self, ops, group=None, world=1, rank=0):
         self.ops, self.group, self.world, self.rank = ops, group, world, rank
         self.staged = False
+        self.rounds = 0  # neighbour exchanges + all-gathers issued so far (diagnostics)
         if world > 1:
             backend = dist.get_backend(group)
             self.staged = backend == "gloo" and ops.name == "hip"
@@ -33,6 +33,7 @@ class SlabComm:
         """sends/recvs: lists of (1-D tensor view, group rank).  All of them form one batch."""
         if not sends and not recvs:
             return
+        self.rounds += 1
         with self.ops.ctx():
             if not self.staged:
                 ops_ = [dist.P2POp(dist.isend, t, self._peer(p), self.group) for t, p in sends]
@@ -49,29 +50,22 @@ class SlabComm:
             for h, _, t in host_r:
                 t.copy_(h)
 
-    def gather0(self, src, parts):
-        """Every rank contributes `src`; rank 0 receives them into the list `parts` (else None)."""
+    def allgather_rows(self, out, inp):
+        """out (world*R rows) <- the R rows `inp` of every rank, in rank order; both are whole-row
+        (contiguous) slices of equally wide arrays."""
+        self.rounds += 1
         with self.ops.ctx():
             if not self.staged:
-                dist.gather(src, parts, dst=self._peer(0), group=self.group)
+                if dist.get_backend(self.group) == "nccl":
+                    dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
+                else:
+                    R = inp.shape[0]
+                    dist.all_gather([out[q * R : (q + 1) * R] for q in range(self.world)], inp, group=self.group)
                 return
-            h = src.cpu()
-            hp = [torch.empty_like(h) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(h, hp, dst=self._peer(0), group=self.group)
-            if self.rank == 0:
-                for d, s in zip(parts, hp):
-                    d.copy_(s)
-
-    def scatter0(self, dst, parts):
-        """Rank 0 sends parts[k] to rank k; every rank receives into `dst`."""
-        with self.ops.ctx():
-            if not self.staged:
-                dist.scatter(dst, parts, src=self._peer(0), group=self.group)
-                return
-            h = torch.empty(dst.shape, dtype=dst.dtype)
-            hp = [p.cpu() for p in parts] if self.rank == 0 else None
-            dist.scatter(h, hp, src=self._peer(0), group=self.group)
-            dst.copy_(h)
+            h = inp.cpu()
+            hp = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(hp, h, group=self.group)
+            out.copy_(torch.cat(hp, 0))
 
     def allreduce_max(self, t):
         """In-place MAX over ranks of a small NaN-free tensor; returns it."""

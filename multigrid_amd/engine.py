@@ -18,9 +18,12 @@ What differs from the reference is where the data lives and how it is cut:
   fused pass over memory (mg_smooth_fused); with several ranks the halo is as deep as the pass
   (H = 8), each rank recomputes the few rows next to its slab that the pass needs, and the halo
   is exchanged once per pass instead of once per sweep;
-* the whole-domain levels live on rank 0 only: their right-hand side is gathered there, the tail
-  runs as one hipGraph, and the correction is scattered back (the reference replicates the tail on
-  every rank behind four broadcasts, :117-138);
+* only the Jacobi levels whose slabs are tall enough to be worth an exchange are distributed; from
+  the first level with fewer than `dist_min_rows` rows per rank on, one all-gather of the right-hand
+  side gives every rank the whole grid, and every rank runs the remaining Jacobi levels and the
+  whole-domain levels redundantly, without any communication, as one hipGraph (the reference also
+  replicates its whole-domain levels on every rank, behind four broadcasts, :117-138).  The
+  correction a rank needs is then a row window of its own copy;
 * Jacobi sweeps ping-pong between two arrays instead of copying a scratch array back;
 * on one GPU the whole V-cycle is captured once into a hipGraph and replayed per cycle.
 
@@ -43,7 +46,7 @@ class SlabMultigrid:
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
-                 store_residual_every_cycle=False, batch=None):
+                 store_residual_every_cycle=False, batch=None, dist_min_rows=256):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -56,7 +59,18 @@ class SlabMultigrid:
         self.fused = fused and getattr(ops, "supports_fused", False)
         if halo is None and world > 1 and not self.fused:
             halo = 2  # one exchange per sweep needs one row; 2 keeps the halo even
-        self.plan = make_plan(gny, gnx, n_para, world, rank, h0, halo)
+        # Jacobi levels 0 .. n_dist-1 are distributed, the others replicated on every rank
+        n_dist = n_para
+        if world > 1:
+            H_ = halo if halo is not None else 8
+            R0 = (gny - 1) // world
+            n_dist = max(1, sum(1 for l in range(n_para) if (R0 >> l) >= max(dist_min_rows, H_)))
+        self.n_dist = n_dist
+        self.plan = make_plan(gny, gnx, n_para, world, rank, h0, halo, n_dist=n_dist)
+        # the same grid on one rank, with the same halo depth: layout of the replicated levels; a
+        # rank's slab window of such an array (its rows plus the halo rows) is a row range of it
+        self.gplan = self.plan if world == 1 else make_plan(gny, gnx, n_para, 1, 0, h0, self.plan.halo)
+        self.lv = [(self.plan if l < n_dist else self.gplan).levels[l] for l in range(n_para + 1)]
         W0 = self.plan.whole[0]
         if rank == 0 and coarse_ordering == "lexicographic" and not whole_level_fits_lds(W0.ny, W0.nx):
             warnings.warn(f"the first whole-domain level ({W0.ny} x {W0.nx}) does not fit LDS: its SSOR wavefront will walk "
@@ -88,41 +102,30 @@ class SlabMultigrid:
         self.batch = batch
         z = (lambda rows, ld: ops.zeros(rows, ld, batch)) if batch is not None else ops.zeros
         # Jacobi levels: two x arrays (ping-pong), b, r.  b has one more level (the staging level).
-        self._xa = [z(L.ny, L.ld) for L in P.levels[:n_para]]
-        self._xb = [z(L.ny, L.ld) for L in P.levels[:n_para]]
-        self.b = [z(L.ny, L.ld) for L in P.levels]
-        self.r = [z(L.ny, L.ld) for L in P.levels[:n_para]]
+        LV = self.lv
+        self._xa = [z(L.ny, L.ld) for L in LV[:n_para]]
+        self._xb = [z(L.ny, L.ld) for L in LV[:n_para]]
+        self.b = [z(L.ny, L.ld) for L in LV]
+        self.r = [z(L.ny, L.ld) for L in LV[:n_para]]
+        # the last distributed level restricts into a slab, which is all-gathered into b[n_dist]
+        self._bslab = z(P.levels[n_dist].ny, P.levels[n_dist].ld) if world > 1 else None
         self._cur0 = 0  # which of (_xa[0], _xb[0]) holds the finest x
         self.norm = ops.norm_slots()
-        # Whole-domain levels (rank 0).  The first one is laid out like a slab that spans all ranks:
-        # local row t of it is global row t - H, so that every rank's window of the correction
-        # (its rows plus H halo rows each side) is a contiguous row range of one padded array.
+        # Whole-domain levels, on every rank.  The first one shares the rows of the (replicated)
+        # staging level: local row t of the padded arrays is global row t - H.
         self.xw, self.bw, self.rw = [], [], []
-        S, W0 = P.levels[n_para], P.whole[0]
-        if world == 1:
-            self._xw0_pad = z(S.ny, S.ld)
-            self.xw.append(self._xw0_pad[..., H : H + W0.ny, :])
-            self.bw.append(self.b[n_para][..., H : H + W0.ny, :])
-            # the same window of an equally padded array: one batch stride for all arrays of a launch
-            self.rw.append(z(S.ny, S.ld)[..., H : H + W0.ny, :])
-        elif rank == 0:
-            self._xw0_pad = z(W0.ny + 2 * H, W0.ld)
-            self.xw.append(self._xw0_pad[H : H + W0.ny])
-            self.bw.append(z(W0.ny, W0.ld))
-            self.rw.append(z(W0.ny, W0.ld))
-        if rank == 0:
-            for W in P.whole[1:]:
-                self.xw.append(z(W.ny, W.ld))
-                self.bw.append(z(W.ny, W.ld))
-                self.rw.append(z(W.ny, W.ld))
-        if world > 1:
-            self._gather_buf = z(world * S.ny, S.ld) if rank == 0 else None
-            self._scatter_buf = z(world * S.ny, S.ld) if rank == 0 else None
-            # the correction lands in a slab of its own: with one Jacobi level the pass that prolongs it
-            # also writes the staging level's right-hand side
-            self._corr = z(S.ny, S.ld)
+        S, W0 = LV[n_para], P.whole[0]
+        self._xw0_pad = z(S.ny, S.ld)
+        self.xw.append(self._xw0_pad[..., H : H + W0.ny, :])
+        self.bw.append(self.b[n_para][..., H : H + W0.ny, :])
+        # the same window of an equally padded array: one batch stride for all arrays of a launch
+        self.rw.append(z(S.ny, S.ld)[..., H : H + W0.ny, :])
+        for W in P.whole[1:]:
+            self.xw.append(z(W.ny, W.ld))
+            self.bw.append(z(W.ny, W.ld))
+            self.rw.append(z(W.ny, W.ld))
         self._graphs = {}
-        self._tail_graph = None
+        self._mid_graph = None
         self._dead_graph = None
         self._b0_halo_valid = False
         self._r0_stale = False
@@ -226,32 +229,38 @@ class SlabMultigrid:
         one that holds the result.  Halo rows of the result are NOT valid.  restrict=True also
         produces b_{l+1} from the residual (:273, :288), fused into the pass when passes are fused (the
         residual is then stored only if `r` is given)."""
-        L, o = self.plan.levels[l], self.ops
+        L, o = self.lv[l], self.ops
         xa, xb = self._xa[l], self._xb[l]
-        cnx = self.plan.levels[l + 1].nx
+        cnx = self.lv[l + 1].nx
+        dist_ = self.world > 1 and l < self.n_dist           # this level is cut into slabs
+        to_rep = dist_ and l + 1 == self.n_dist              # ... and the next one is replicated
+        # where the restriction goes: the next level's b, or the slab that is then all-gathered into it
+        Lc = self.plan.levels[l + 1] if to_rep else self.lv[l + 1]
+        cb = self._bslab if to_rep else self.b[l + 1]
         if self.fused:
             extra = (2 if restrict else 1 if r is not None else 0)
-            chunks = self._chunks(n, min(6, L.halo - extra) if self.world > 1 else 6)
-            Lc = self.plan.levels[l + 1]
+            chunks = self._chunks(n, min(6, L.halo - extra) if dist_ else 6)
             for ci, k in enumerate(chunks):
                 dst = xa if (src is None or src is xb) else xb
                 first, last = ci == 0, ci == len(chunks) - 1
                 depth = k + (extra if last else 0)
-                if src is not None:  # the pass reads `depth` rows beyond the rows it produces
+                if src is not None and dist_:  # the pass reads `depth` rows beyond the rows it produces
                     items = [(src, L, depth)]
                     if first and crs is not None and not crs_has_halo:
-                        items.append((crs, self.plan.levels[l + 1], depth // 2 + 2))
+                        items.append((crs, self.lv[l + 1], depth // 2 + 2))
                     self._exchange(items)
                 if last and norm is not None:
                     o.norm_reset(norm)
                 if last and restrict:
                     o.smooth_fused(self.b[l], src, dst, r, crs if first else None, L.nx, cnx, L.t0, L.t1, L.fix_lo,
-                                   L.fix_hi, L.oj, k, L.h, norm, self.b[l + 1], Lc.nx, Lc.t0, Lc.t1)
+                                   L.fix_hi, L.oj, k, L.h, norm, cb, Lc.nx, Lc.t0, Lc.t1)
                 else:
                     o.smooth_fused(self.b[l], src, dst, r if last else None, crs if first else None, L.nx, cnx, L.t0,
                                    L.t1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None)
                 src = dst
-            if restrict and l + 1 < self.n_para:
+            if restrict and to_rep:
+                self._allgather_b(l + 1)
+            elif restrict and dist_:
                 self._exchange([(self.b[l + 1], Lc, self.plan.halo - 1)])
             return src
         # one kernel per operation, one single-row exchange per sweep
@@ -261,19 +270,37 @@ class SlabMultigrid:
         else:
             if crs is not None:  # its lower halo row is valid: last exchanged after its last sweep
                 o.prolong_add(crs, cnx, src, L.nx, L.t0, L.t1, 0, L.oj)
-        self._exchange([(src, L, 1)])
+        if dist_:
+            self._exchange([(src, L, 1)])
         for _ in range(n):
             dst = xb if src is xa else xa
             o.jacobi(self.b[l], src, dst, L.nx, L.t0, L.t1, L.h, finest)
-            self._exchange([(dst, L, 1)])
+            if dist_:
+                self._exchange([(dst, L, 1)])
             src = dst
         if r is not None:
             if norm is not None:
                 o.norm_reset(norm)
             o.residual(r, src, self.b[l], L.nx, L.t0, L.t1, L.h, norm, finest)
         if restrict:
-            self._restrict(l)
+            if dist_:  # full weighting needs one halo row of r above
+                self._exchange([(self.r[l], L, 1)], up=True, down=False)
+            o.restrict(self.r[l], L.nx, cb, Lc.nx, Lc.t0, Lc.t1, 0, L.oj)
+            if to_rep:
+                self._allgather_b(l + 1)
         return src
+
+    def _allgather_b(self, lc):
+        """Every rank's owned rows of the slab right-hand side of level lc -> the replicated b[lc]."""
+        H, R = self.plan.halo, self.plan.levels[lc].rows
+        self.comm.allgather_rows(self.b[lc][H : H + self.world * R], self._bslab[H : H + R])
+
+    def _window(self, arr, lc):
+        """This rank's slab of a replicated level-lc array: its rows and the halo rows around them."""
+        if self.world == 1:
+            return arr
+        R = self.plan.levels[lc].rows
+        return arr[self.rank * R : self.rank * R + self.plan.levels[lc].ny]
 
     def _smooth_level0(self, n, want_norm, crs=None, store_r=False):
         xs = [self._xa[0], self._xb[0]]
@@ -284,18 +311,12 @@ class SlabMultigrid:
         # the residual of the finest level is restricted right away: b_1 is ready for the next descent
         store_r = store_r or self.store_residual_every_cycle or not self.fused
         res = self._smooth(0, xs[self._cur0], crs, n, self.r[0] if store_r else None, self.norm if want_norm else None,
-                           finest=True, crs_has_halo=self.n_para == 1, restrict=True)
+                           finest=True, crs_has_halo=self.n_dist == 1, restrict=True)
         self._r0_stale = not store_r
         self._cur0 = 0 if res is xs[0] else 1
 
-    def _restrict(self, l):
-        """r_l -> b_{l+1} (full weighting needs one halo row of r above), then the halo of b_{l+1}."""
-        o, Ls = self.ops, self.plan.levels
-        self._exchange([(self.r[l], Ls[l], 1)], up=True, down=False)
-        o.restrict(self.r[l], Ls[l].nx, self.b[l + 1], Ls[l + 1].nx, Ls[l + 1].t0, Ls[l + 1].t1, 0, Ls[l].oj)
-
     def _tail(self):
-        """Whole-domain levels on rank 0 (parallel_multigrid.py:291-304)."""
+        """First whole-domain level (parallel_multigrid.py:291-293); every rank runs it."""
         o, W = self.ops, self.plan.whole
         nw = len(W)
         o.zero_(self._xw0_pad)
@@ -311,7 +332,7 @@ class SlabMultigrid:
             return
         o = self.ops
         with o.side():
-            if self.use_graph and self.world > 1:
+            if self.use_graph and self.world > 1:  # on one rank they are part of the cycle graph
                 if self._dead_graph is None:
                     o.graph_begin()
                     self._tail_below()
@@ -336,70 +357,60 @@ class SlabMultigrid:
 
     def sync_whole_levels(self):
         """Bring xw[1:], bw[1:], rw[1:] to the state the reference's arrays have after the last cycle
-        (no-op when they are computed every cycle).  Rank 0 holds these levels."""
-        if not self.eager_dead_levels and self.rank == 0 and self.xw:
+        (no-op when they are computed every cycle)."""
+        if not self.eager_dead_levels and len(self.xw) > 1:
             self.ops.begin()
             self._tail_below()
             self.ops.end()
             self.ops.synchronize()
 
-    def _coarse_solve(self):
-        """Gather the staging-level right-hand side to rank 0, run the tail, scatter the correction
-        (every rank's rows plus its halo rows) into the staging slab, which then plays the role of
-        the reference's split(x_wl[0]) (:307).  Returns the slab holding the correction."""
-        o, P = self.ops, self.plan
-        S, H = P.levels[self.n_para], P.halo
-        if self.world == 1:
-            self._run_tail()
-            self._dead_levels()
-            return self._xw0_pad
-        stage = self.b[self.n_para]
-        R = S.rows
-        if self.rank == 0:
-            parts = list(self._gather_buf.view(self.world, S.ny, S.ld).unbind(0))
-            self.comm.gather0(stage, parts)
-            with o.ctx():
-                g = self._gather_buf.view(self.world, S.ny, S.ld)
-                # owned rows of every rank, in order; the last global row is boundary (stays zero)
-                self.bw[0][: self.world * R].view(self.world, R, S.ld).copy_(g[:, H : H + R, :])
-            self._run_tail()
-            with o.ctx():
-                # rank p gets global rows p*R-H .. (p+1)*R+H-1 = padded rows p*R .. p*R+R+2H-1
-                win = self._xw0_pad.as_strided((self.world, S.ny, S.ld), (R * S.ld, S.ld, 1))
-                self._scatter_buf.view(self.world, S.ny, S.ld).copy_(win)
-            self._dead_levels()  # rank 0 only, beside the scatter and the ascent
-            parts = list(self._scatter_buf.view(self.world, S.ny, S.ld).unbind(0))
-            self.comm.scatter0(self._corr, parts)
-        else:
-            self.comm.gather0(stage, None)
-            self.comm.scatter0(self._corr, None)
-        return self._corr
+    def _middle(self):
+        """The part of the cycle that needs no communication: descent of the replicated Jacobi levels,
+        the first whole-domain level, their ascent.  Every rank computes the same values.  Returns
+        the array that holds the correction for the last distributed level."""
+        n_para, k = self.n_para, self.n_dist
+        for l in range(k, n_para):
+            self._smooth(l, None, None, self.N1, None if self.fused else self.r[l], restrict=True)
+        self._tail()
+        corr = self._xw0_pad
+        for l in range(n_para - 1, k - 1, -1):
+            corr = self._smooth(l, self._xa[l], corr, self.N2, self.r[l] if self.keep_ascent_residuals else None,
+                                crs_has_halo=True)
+        return corr
 
-    def _run_tail(self):
-        if not self.use_graph or self.world == 1:  # on one rank the tail is part of the cycle graph
-            self._tail()
-            return
-        if self._tail_graph is None:
-            self.ops.graph_begin()
-            self._tail()
-            self._tail_graph = self.ops.graph_end()
-        self.ops.graph_launch(self._tail_graph)
+    def _run_middle(self):
+        # a from-zero pass always writes _xa[l] and an even number of passes follows on the ascent, so
+        # the result lands in the same array every cycle: one captured graph serves all cycles
+        if not self.use_graph or self.world == 1:  # on one rank the middle is part of the cycle graph
+            self._mid_result = self._middle()
+        else:
+            if self._mid_graph is None:
+                self.ops.graph_begin()
+                self._mid_result = self._middle()
+                self._mid_graph = self.ops.graph_end()
+            self.ops.graph_launch(self._mid_graph)
+        self._dead_levels()
+        return self._mid_result
 
     def _cycle(self, store_r=False):
         """One V-cycle (the body of the loop at parallel_multigrid.py:270-347), norm included.
         store_r: the finest pass also writes the residual array (a caller that knows this is its
         last cycle saves the separate residual launch that way)."""
-        n_para = self.n_para
-        # ---- descent (b_1 was produced together with the finest residual, by presmooth or the last cycle)
-        for l in range(1, n_para):
+        k = self.n_dist
+        # ---- descent of the distributed levels (b_1 was produced together with the finest residual, by
+        # presmooth or the last cycle); the last one ends with the all-gather of b_k
+        for l in range(1, k):
             self._smooth(l, None, None, self.N1, None if self.fused else self.r[l], restrict=True)
-        # ---- coarse
-        corr = self._coarse_solve()
-        # ---- ascent
-        for l in range(n_para - 1, 0, -1):
+        # ---- everything below, on every rank alike
+        corr = self._run_middle()
+        # ---- ascent of the distributed levels: the first takes its window of the replicated result
+        for l in range(k - 1, 0, -1):
             # x_l of the descent is in _xa[l] (a from-zero pass always writes there)
-            corr = self._smooth(l, self._xa[l], corr, self.N2, self.r[l] if self.keep_ascent_residuals else None,
-                                crs_has_halo=l == n_para - 1)
+            rep = l + 1 == k
+            corr = self._smooth(l, self._xa[l], self._window(corr, l + 1) if rep else corr, self.N2,
+                                self.r[l] if self.keep_ascent_residuals else None, crs_has_halo=rep)
+        if k == 1:
+            corr = self._window(corr, 1)
         self._smooth_level0(self.N2, want_norm=True, crs=corr, store_r=store_r)
         self.ops.join_side()
 
@@ -490,7 +501,7 @@ class SlabMultigrid:
         for g, _ in self._graphs.values():
             self.ops.graph_destroy(g)
         self._graphs = {}
-        for name in ("_tail_graph", "_dead_graph"):
+        for name in ("_mid_graph", "_dead_graph"):
             if getattr(self, name, None) is not None:
                 self.ops.graph_destroy(getattr(self, name))
                 setattr(self, name, None)

@@ -95,7 +95,7 @@ class SlabPlan:
         return (self.gny - 2) * (self.gnx - 2)
 
 
-def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0, halo=None):
+def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0, halo=None, n_dist=None):
     """Partition a (gny x gnx) grid (boundary included) for `n_para` Jacobi levels over `world` ranks.
 
     Requirements: gny-1 = world * R with R divisible by 2**n_para (so that coarse row g/2 lives on
@@ -104,22 +104,28 @@ def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0, halo=None):
     `halo`: rows of halo per side; default 1 on one rank (nothing is exchanged), 8 on several (deep
     enough for a fused pass of 6 sweeps + residual, and even, which keeps the fine/coarse row
     correspondence t = 2T - halo on every level).
+    `n_dist`: how many of the Jacobi levels (the finest ones) are actually cut into slabs; the
+    per-rank requirements apply to those only (default: all).
     """
+    n_dist = n_para if n_dist is None else n_dist
     if n_para < 1:
         raise ValueError("n_para >= 1 required")
     if (gny - 1) % world:
         raise ValueError(f"{gny - 1} rows of cells cannot be split evenly over {world} ranks")
     R0 = (gny - 1) // world
-    if R0 % (1 << n_para) or (gnx - 1) % (1 << n_para):
-        raise ValueError(f"rows per rank ({R0}) and columns-1 ({gnx - 1}) must be divisible by 2**n_para = {1 << n_para}")
+    if (gny - 1) % (1 << n_para) or (gnx - 1) % (1 << n_para):
+        raise ValueError(f"rows-1 ({gny - 1}) and columns-1 ({gnx - 1}) must be divisible by 2**n_para = {1 << n_para}")
+    if R0 % (1 << n_dist):
+        raise ValueError(f"rows per rank ({R0}) must be divisible by 2**{n_dist} (slab boundaries on even rows of "
+                         "every distributed level and of the first replicated one)")
     if ((gny - 1) >> n_para) < 2 or ((gnx - 1) >> n_para) < 2:
         raise ValueError("the first whole-domain level needs at least 2 cells per side")
     H = (1 if world == 1 else 8) if halo is None else halo
     if H != 1 and H % 2:
         raise ValueError("halo must be 1 or even")
-    if world > 1 and (R0 >> (n_para - 1)) < H:
-        raise ValueError(f"the coarsest Jacobi level has {R0 >> (n_para - 1)} rows per rank, fewer than the halo depth {H}: "
-                         "use fewer Jacobi levels (n_para), fewer ranks or a smaller halo")
+    if world > 1 and (R0 >> (n_dist - 1)) < H:
+        raise ValueError(f"the coarsest distributed level has {R0 >> (n_dist - 1)} rows per rank, fewer than the halo depth "
+                         f"{H}: distribute fewer levels, use fewer ranks or a smaller halo")
     plan = SlabPlan(gny, gnx, n_para, world, rank, h0, H)
     last = rank == world - 1
     for l in range(n_para + 1):
@@ -141,11 +147,13 @@ def make_plan(gny, gnx, n_para, world=1, rank=0, h0=1.0, halo=None):
     return plan
 
 
-def exchanges_per_cycle(n_para, fused=True):
-    """Halo exchange rounds one V-cycle performs per rank (see engine.SlabMultigrid._cycle): with
-    fused passes one round of r, one of b and one of (x, correction) per Jacobi level; with one
-    exchange per sweep 8 on the finest level and 11 on each of the others."""
-    return 3 * n_para if fused else 8 + 11 * (n_para - 1)
+def exchanges_per_cycle(n_dist, fused=True):
+    """Communication rounds one V-cycle performs per rank with n_dist distributed Jacobi levels (see
+    engine.SlabMultigrid._cycle), the max-reduction of the norm not counted.  Fused passes: per level
+    one halo exchange of (x, correction) before the ascent pass and one of the restricted right-hand
+    side after the descent pass (for the last distributed level that one is the all-gather).  One
+    kernel per operation: an exchange per sweep and one of r per restriction."""
+    return 2 * n_dist if fused else 8 + 11 * (n_dist - 1) + 1
 
 
 def algorithmic_bytes_per_cycle(plan, keep_ascent_residuals=False, fused_zero_sweep=True):

@@ -121,7 +121,7 @@ def test_plan_and_layout():
         make_plan(65, 65, 6)
     with pytest.raises(ValueError):
         make_plan(67, 65, 2)
-    assert exchanges_per_cycle(4, fused=False) == 8 + 33 and exchanges_per_cycle(4) == 12
+    assert exchanges_per_cycle(4, fused=False) == 8 + 33 + 1 and exchanges_per_cycle(4) == 8
 
 
 # ------------------------------------------------------------------ multi-rank, gloo
@@ -135,23 +135,32 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True):
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, dist_min_rows=256):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, world, rank, cycles, fused=fused)
+        eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, world, rank, cycles, fused=fused,
+                                      dist_min_rows=dist_min_rows)
+        # communication rounds of one more cycle (its last pass also stores r: no extra round)
+        before = eng.comm.rounds
+        eng.cycles(1)
+        assert eng.comm.rounds - before == exchanges_per_cycle(eng.n_dist, fused), (eng.n_dist, eng.comm.rounds - before)
         q.put((rank, errs, x, r))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
+# dist_min_rows: Jacobi levels with fewer rows per rank are replicated on every rank instead of being
+# cut into slabs (8 = the halo depth: as many distributed levels as possible; 256 = the default, which
+# at these sizes leaves only the finest level distributed)
+@pytest.mark.parametrize("dist_min_rows", [8, 16, 256])
 @pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 65, 65, 2, True), (2, 65, 33, 1, True), (2, 129, 65, 3, True), (2, 129, 65, 3, False),
                                                         (4, 129, 129, 3, True), (4, 257, 33, 2, True),
                                                         (4, 257, 33, 2, False)], ids=str)
-def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused):
+def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused, dist_min_rows):
     b = _rhs(gny, gnx, 7)
     h = 0.37
     cycles = 3
@@ -161,7 +170,7 @@ def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused))
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows))
              for rk in range(world)]
     for p in procs:
         p.start()

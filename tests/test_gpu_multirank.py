@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused):
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -30,7 +30,8 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused):
     try:
         from multigrid_amd.engine import SlabMultigrid
         # dead whole-domain levels every cycle for the larger grids: rank 0 runs them as a graph on a side stream
-        eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank, fused=fused, eager_dead_levels=gny > 300)
+        eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank, fused=fused, eager_dead_levels=gny > 300,
+                            dist_min_rows=dist_min_rows)
         assert eng.comm.staged
         R = eng.plan.levels[0].rows
         a, e = eng.owned_rows()
@@ -48,7 +49,8 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused):
 
 @pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 257, 257, 3, True), (2, 129, 97, 1, True), (4, 1025, 513, 5, True),
                                                         (3, 769, 300 * 4 + 1, 2, True), (4, 1025, 513, 5, False)], ids=str)
-def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para, fused):
+@pytest.mark.parametrize("dist_min_rows", [8, 64])
+def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para, fused, dist_min_rows):
     import torch.multiprocessing as mp
     rng = np.random.default_rng(1)
     b = rng.standard_normal((gny, gnx))
@@ -61,7 +63,7 @@ def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para, fused):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused))
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows))
              for rk in range(world)]
     for p in procs:
         p.start()
