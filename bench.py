@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--exp", dest="n", type=int, default=14, help="grid is (2**(n+1)+1) columns wide; 14 -> 32769")
     ap.add_argument("--jacobi-levels", dest="n_para", type=int, default=0,
                     help="number of Jacobi (slab-distributed) levels; 0 = 8, or more where the first whole-domain level "
-                         "(which grows with the rank count) would not fit LDS otherwise: 9 on 2 and 4 ranks, 10 on 8")
+                         "(which grows with the rank count) would leave the single-wave SSOR kernel otherwise: 9, 10, 11 on 2, 4, 8 ranks")
     ap.add_argument("--ordering", default="lexicographic", choices=["lexicographic", "redblack"])
     ap.add_argument("--roofline-iters", type=int, default=20)
     ap.add_argument("--cpu-exp", dest="cpu_n", type=int, default=12, help="grid exponent of the CPU baseline sample")

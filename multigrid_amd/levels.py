@@ -183,9 +183,14 @@ def whole_level_fits_lds(ny, nx):
     return ny * ((nx + 1) & ~1) <= SOR_LDS_DOUBLES
 
 
+def whole_level_fits_one_wave(ny, nx):
+    """True when that SSOR runs on the barrier-free single-wave kernel (at most two rows per lane)."""
+    return whole_level_fits_lds(ny, nx) and ny - 1 <= 128
+
+
 def choose_n_para(gny, gnx, world=1, at_least=1):
     """Smallest number of Jacobi levels >= at_least that make_plan accepts for this grid and rank
-    count and whose first whole-domain level fits LDS.  On a grid that grows with the rank count
+    count and whose first whole-domain level runs on the fastest SSOR kernel (LDS-resident, one wave).  On a grid that grows with the rank count
     (weak scaling over rows) that level grows too, so more ranks want more Jacobi levels."""
     n_para = at_least
     while True:
@@ -193,6 +198,6 @@ def choose_n_para(gny, gnx, world=1, at_least=1):
             plan = make_plan(gny, gnx, n_para, world, 0)
         except ValueError:
             return None
-        if whole_level_fits_lds(plan.whole[0].ny, plan.whole[0].nx):
+        if whole_level_fits_one_wave(plan.whole[0].ny, plan.whole[0].nx):
             return n_para
         n_para += 1

@@ -214,14 +214,14 @@ def test_batch_of_problems_equals_independent_solves():
 
 
 def test_choose_n_para_keeps_the_whole_domain_level_in_lds():
-    from multigrid_amd.levels import choose_n_para, make_plan, whole_level_fits_lds
-    for world, want in ((1, 8), (2, 9), (4, 9), (8, 10)):
+    from multigrid_amd.levels import choose_n_para, make_plan, whole_level_fits_one_wave
+    for world, want in ((1, 8), (2, 9), (4, 10), (8, 11)):
         gny, gnx = world * 2 ** 15 + 1, 2 ** 15 + 1
         n_para = choose_n_para(gny, gnx, world, at_least=8)
         assert n_para == want
         W0 = make_plan(gny, gnx, n_para, world, 0).whole[0]
-        assert whole_level_fits_lds(W0.ny, W0.nx)
+        assert whole_level_fits_one_wave(W0.ny, W0.nx)
         if n_para > 8:
             W0 = make_plan(gny, gnx, n_para - 1, world, 0).whole[0]
-            assert not whole_level_fits_lds(W0.ny, W0.nx)
+            assert not whole_level_fits_one_wave(W0.ny, W0.nx)
     assert choose_n_para(9, 9, 1, at_least=1) == 1
