@@ -1,0 +1,98 @@
+"""Parity at the benchmark's own sizes (marked gpu).
+
+The CPU oracle takes seconds per V-cycle at 16385^2 and the level arrays take 46 GB at 32769^2, so the
+largest grid is covered through properties that do not need the oracle:
+  * two independent code paths of this package -- fused passes inside one hipGraph vs. one kernel per
+    operation, launched eagerly -- agree bit for bit;
+  * the stored residual equals b - A x recomputed by the single-operation kernel, and the reported
+    norm equals its max-norm;
+  * scaling the right-hand side by a power of two scales the solution by exactly that factor
+    (every operation of the cycle is linear and a power-of-two factor commutes with rounding).
+One size down (16385^2, BASELINE's 8-GPU configuration run on one GPU) the engine is compared with
+the oracle itself, bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(n, n_para, **kw):
+    import torch
+    import bench
+    from multigrid_amd.engine import SlabMultigrid
+    N = 2 ** (n + 1) + 1
+    eng = SlabMultigrid(N, N, n_para, 20.0 / 2 ** (n + 1), 0.0, world=1, rank=0, **kw)
+    bench.fill_rhs(eng, torch, n, 0)
+    return eng
+
+
+def test_fused_graph_equals_separate_kernels_at_32769():
+    import torch
+    n, n_para = 14, 8
+    a = _engine(n, n_para, eager_dead_levels=True)
+    a.presmooth()
+    ea = a.cycles(2)
+    xa = a.x0.clone()
+    ra = a.r0.clone()
+    a.close()
+    del a
+    torch.cuda.empty_cache()
+    b = _engine(n, n_para, fused=False, use_graph=False)
+    b.presmooth()
+    eb = b.cycles(2)
+    assert ea == eb
+    assert torch.equal(xa, b.x0)
+    assert torch.equal(ra, b.r0)
+    # the stored residual is b - A x, and the reported norm its max-norm
+    L = b.plan.levels[0]
+    chk = torch.zeros_like(ra)
+    b.ops.begin()
+    b.ops.residual(chk, b.x0, b.b0, L.nx, L.t0, L.t1, L.h)
+    b.ops.end()
+    torch.cuda.synchronize()
+    assert torch.equal(chk, ra)
+    assert float(ra.abs().max()) == ea[-1]
+    b.close()
+
+
+def test_power_of_two_scaling_is_exact_at_32769():
+    import torch
+    n, n_para = 14, 8
+    e = _engine(n, n_para)
+    e.presmooth()
+    e1 = e.cycles(2)
+    x1 = e.x0.clone()
+    # same engine, right-hand side times 4, x back to zero
+    e.b0.mul_(4.0)
+    e.set_b_rows(e.local_rows(e.b0).clone())
+    e.set_x_rows(torch.zeros_like(e.local_rows(e.x0)))
+    e.presmooth()
+    e4 = e.cycles(2)
+    assert e4 == [4.0 * v for v in e1]
+    assert torch.equal(e.x0, 4.0 * x1)
+    e.close()
+
+
+def test_engine_equals_oracle_at_16385():
+    import torch
+    n, n_para = 13, 7
+    e = _engine(n, n_para, eager_dead_levels=True)
+    N = e.plan.gnx
+    ref = oracle.GlobalSolver(N, N, n_para, 20.0 / 2 ** (n + 1), 0.0)
+    ref.b[:] = e.local_rows(e.b0).cpu().numpy()
+    ref.solve(ncycles=2)
+    e.presmooth()
+    errs = e.cycles(2)
+    assert errs == ref.err_hist.tolist()
+    assert np.array_equal(e.local_rows(e.x0).cpu().numpy(), ref.x)
+    assert np.array_equal(e.local_rows(e.r0).cpu().numpy(), ref.r)
+    e.close()
