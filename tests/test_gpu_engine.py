@@ -258,3 +258,49 @@ def test_rectangular_and_nan():
     b[40, 40] = np.nan
     eng2 = _make(129, 513, 3, 0.1, 1e-3, b)
     assert np.isnan(eng2.solve())
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_nonzero_dirichlet_boundary(fused):
+    """Boundary values of x are data: they enter the finest-level sweeps and residual and are never
+    changed (the corrections of the coarser levels have zero boundaries).  Engine == oracle bit for
+    bit, and the converged solution solves the Dirichlet problem with those boundary values."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import torch
+    gny, gnx, n_para, h = 65, 129, 3, 0.05
+    rng = np.random.default_rng(12)
+    b = _rhs(gny, gnx, 12)
+    x0 = np.zeros((gny, gnx))
+    x0[0], x0[-1], x0[:, 0], x0[:, -1] = (rng.standard_normal(gnx), rng.standard_normal(gnx), rng.standard_normal(gny),
+                                           rng.standard_normal(gny))
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0)
+    ref.b[:] = b
+    ref.x[:] = x0
+    ref.solve(ncycles=4)
+    eng = _make(gny, gnx, n_para, h, 0.0, b, fused=fused)
+    eng.set_x_rows(torch.from_numpy(x0).cuda())
+    eng.presmooth()
+    assert eng.cycles(4) == ref.err_hist.tolist()
+    assert np.array_equal(_rows(eng, eng.x0), ref.x)
+    assert np.array_equal(_rows(eng, eng.r0), ref.r)
+    # direct solve: A x_int = b_int - (boundary contributions) / h^2
+    my, mx = gny - 2, gnx - 2
+    Ty = sp.diags([np.ones(my - 1), -2 * np.ones(my), np.ones(my - 1)], [-1, 0, 1])
+    Tx = sp.diags([np.ones(mx - 1), -2 * np.ones(mx), np.ones(mx - 1)], [-1, 0, 1])
+    A = (sp.kron(Ty, sp.identity(mx)) + sp.kron(sp.identity(my), Tx)) / h ** 2
+    rhs = b[1:-1, 1:-1].copy()
+    rhs[0] -= x0[0, 1:-1] / h ** 2
+    rhs[-1] -= x0[-1, 1:-1] / h ** 2
+    rhs[:, 0] -= x0[1:-1, 0] / h ** 2
+    rhs[:, -1] -= x0[1:-1, -1] / h ** 2
+    x_direct = x0.copy()
+    x_direct[1:-1, 1:-1] = spla.spsolve(A.tocsc(), rhs.ravel()).reshape(my, mx)
+    err, total = 1.0, 0
+    while err > 1e-9 and total < 40000:
+        err = eng.cycles(500)[-1]
+        total += 500
+    x = _rows(eng, eng.x0)
+    rel = np.linalg.norm(x - x_direct) / np.linalg.norm(x_direct)
+    assert rel < 1e-10, (total, err, rel)
+    eng.close()
