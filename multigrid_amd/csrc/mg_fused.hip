@@ -496,7 +496,9 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     a.ncb = (a.ntc + 3) / 4;
     int rpb = g_fused_rows;
     if (rpb <= 0) {
-        rpb = 64; // measured at 32769 x 32769: 64-row tiles are as fast as or faster than taller ones at every depth
+        // measured at 32769 x 32769 (profiles/): 64-row tiles are as fast as or faster than taller ones at
+        // every depth, 32-row tiles faster still for the shallow from-zero pass
+        rpb = D <= 5 ? 32 : 64;
         while (rpb > 8 * D && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) * a.nbatch < 2048) rpb >>= 1;
     }
     a.rpb = rpb;

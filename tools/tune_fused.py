@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--rows", type=int, nargs="*", default=[128, 256, 512, 1024])
     ap.add_argument("--unroll", type=int, nargs="*", default=[1, 2])
+    ap.add_argument("--only", nargs="*", default=None, help="kernel names to time (default: all)")
     args = ap.parse_args()
     import torch
     from multigrid_amd import _lib
@@ -64,6 +65,8 @@ def main():
         "0+3J+RS": (18, 16 + 48 + 24 + 10, f(3, False, True, False, True)),
         "1J+RS": (26, 24 + 24 + 10, f(1, False, False, False, True)),
     }
+    if args.only:
+        kernels = {k: v for k, v in kernels.items() if k in args.only}
     configs = list(itertools.product(args.unroll, args.rows))
     results = {}
     for rnd in range(args.rounds):
