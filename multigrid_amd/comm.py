@@ -29,18 +29,26 @@ class SlabComm:
     def _peer(self, r):
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
-    def sendrecv(self, sends, recvs):
-        """sends/recvs: lists of (1-D tensor view, group rank).  All of them form one batch."""
-        if not sends and not recvs:
+    def prepare(self, sends, recvs):
+        """sends/recvs: lists of (1-D tensor view, group rank).  Returns a batch that run() can issue any
+        number of times (the views stay bound to their arrays)."""
+        if self.staged:
+            return ("staged", list(sends), list(recvs))
+        ops_ = [dist.P2POp(dist.isend, t, self._peer(p), self.group) for t, p in sends]
+        ops_ += [dist.P2POp(dist.irecv, t, self._peer(p), self.group) for t, p in recvs]
+        return ("direct", ops_)
+
+    def run(self, batch):
+        """Issue all sends and receives of a prepared batch as one group."""
+        if len(batch[1]) == 0 and (batch[0] == "direct" or len(batch[2]) == 0):
             return
         self.rounds += 1
         with self.ops.ctx():
-            if not self.staged:
-                ops_ = [dist.P2POp(dist.isend, t, self._peer(p), self.group) for t, p in sends]
-                ops_ += [dist.P2POp(dist.irecv, t, self._peer(p), self.group) for t, p in recvs]
-                for w in dist.batch_isend_irecv(ops_):
+            if batch[0] == "direct":
+                for w in dist.batch_isend_irecv(batch[1]):
                     w.wait()
                 return
+            _, sends, recvs = batch
             host_s = [(t.cpu(), p) for t, p in sends]  # .cpu() waits for the kernels that produced the rows
             host_r = [(torch.empty(t.shape, dtype=t.dtype), p, t) for t, p in recvs]
             ops_ = [dist.P2POp(dist.isend, h, self._peer(p), self.group) for h, p in host_s]
@@ -49,6 +57,9 @@ class SlabComm:
                 w.wait()
             for h, _, t in host_r:
                 t.copy_(h)
+
+    def sendrecv(self, sends, recvs):
+        self.run(self.prepare(sends, recvs))
 
     def allgather_rows(self, out, inp):
         """out (world*R rows) <- the R rows `inp` of every rank, in rank order; both are whole-row
@@ -68,7 +79,7 @@ class SlabComm:
             out.copy_(torch.cat(hp, 0))
 
     def allreduce_max(self, t):
-        """In-place MAX over ranks of a small NaN-free tensor; returns it."""
+        """In-place MAX over ranks of a small tensor (integers, or NaN-free floats); returns it."""
         with self.ops.ctx():
             if not self.staged:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)

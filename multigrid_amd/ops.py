@@ -169,11 +169,6 @@ class HipOps:
         check(self.L.mg_norm_read(slots.data_ptr(), C.byref(out), self._s))
         return out.value
 
-    def norm_tensor(self, slots):
-        """the accumulator's max as a 1-element device tensor (no host sync), for a collective"""
-        with torch.cuda.stream(self.stream):
-            return slots.view(torch.float64).max().reshape(1)
-
     # ---- hipGraph ----------------------------------------------------------------------------
     supports_graphs = True
 

@@ -158,6 +158,3 @@ class OracleOps:
 
     def norm_read(self, slots):
         return float(slots.view(torch.float64)[0].item())
-
-    def norm_tensor(self, slots):
-        return slots.view(torch.float64)[:1].clone()
