@@ -117,13 +117,26 @@ def cpu_baseline(args):
     s.solve(ncycles=cycles)
     dt = time.perf_counter() - t0
     unknowns = (N - 2) * (N - 2)
-    return {
+    out = {
         "value": unknowns * cycles / dt, "unit": "unknowns*V-cycles/s", "cores": oracle.num_threads(),
         "kind": "port",
         "sample": f"{cycles} V-cycles on a {N}x{N} grid (n={n}, n_para={n_para}), C restatement of the reference "
                   f"algorithm with OpenMP row-parallel sweeps, {dt:.1f} s",
         "ms_per_cycle": 1e3 * dt / cycles,
     }
+    # the same on 4 threads: the reference itself runs on exactly 4 MPI ranks
+    allthreads = oracle.num_threads()
+    try:
+        oracle.set_num_threads(4)
+        c4 = max(2, min(cycles, int(8.0 / max(t1 * allthreads / 4, 1e-3))))
+        t0 = time.perf_counter()
+        s.solve(ncycles=c4)
+        d4 = time.perf_counter() - t0
+        out["four_workers"] = {"value": unknowns * c4 / d4, "cores": 4, "ms_per_cycle": 1e3 * d4 / c4,
+                               "sample": f"{c4} V-cycles of the same run on 4 threads (the reference runs 4 MPI ranks), {d4:.1f} s"}
+    finally:
+        oracle.set_num_threads(allthreads)
+    return out
 
 
 def main():

@@ -68,6 +68,7 @@ def lib():
         L.orc_global_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_global_solve.restype = C.c_int
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -114,6 +115,10 @@ def interpolate_add_to(a, a_new, ofst_i, ofst_j):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
 
 
 def maxabs(a):

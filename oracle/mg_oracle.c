@@ -35,6 +35,17 @@
 
 typedef int64_t i64;
 
+/* limit the row-parallel loops below to n host threads (timing the algorithm on as many workers
+ * as the reference runs MPI ranks: 4) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* number of host threads the row-parallel loops below use */
 int orc_num_threads(void)
 {
