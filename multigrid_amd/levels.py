@@ -6,7 +6,8 @@ Two layouts appear in this package:
   whole-domain levels of side 2**(n-i)+1 for i = n_para-1 .. n-1
   (Multigrid.__init__, core/parallel_multigrid.py:182-219 of the reference checkout);
 * this package's: the global (NY x NX) grid, boundary included, cut into P row slabs for the
-  n_para Jacobi levels; every coarser grid lives whole on rank 0.
+  finest Jacobi levels; the coarser Jacobi levels and every whole-domain level are held whole by
+  every rank.
 
 `reference_layout` restates the first (used by the drop-in `Multigrid` and by tests),
 `SlabPlan` describes the second.
@@ -71,7 +72,7 @@ class SlabLevel:
 
 @dataclass
 class WholeLevel:
-    """A grid that lives whole on rank 0 (the reference's x_wl/b_wl/r_wl levels)."""
+    """A grid every rank holds whole (the reference's x_wl/b_wl/r_wl levels)."""
     ny: int
     nx: int
     ld: int
