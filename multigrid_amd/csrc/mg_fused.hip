@@ -126,7 +126,11 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
     u64 nmax = 0;
 
     if (active && rb < re) { // uniform per wave
-        double w[D][3][U][2]; // w[s]: stage-s values of three consecutive rows, slots rotating (see step)
+        // w[s]: stage-s values of consecutive rows, slots rotating (see step).  Stages >= 1 keep three
+        // rows (slots 0..2).  Stage 0 keeps six: the three-row window and the three rows being loaded
+        // ahead -- a loaded row is used where it landed, so no value in flight is ever copied, which
+        // would make the copy wait for the whole load queue.
+        double w[D][6][U][2];
         // b of the rows in flight: row i-s for stage s.  Shallow pipelines shift it through registers
         // (br[d]: b of row i-1-d).  Deep ones keep it in LDS instead, 28 VGPRs and 14 moves per step
         // less: a ring of NG groups of three row slots per wave; a step with rotation R writes row i-1
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
 #pragma unroll
         for (int s = 0; s < D; ++s)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < (s == 0 ? 6 : 3); ++q)
 #pragma unroll
                 for (int g = 0; g < U; ++g) w[s][q][g][0] = w[s][q][g][1] = 0.0;
 #pragma unroll
@@ -193,75 +197,74 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
         for (int q = 0; q < (RESTRICT ? 3 : 1); ++q)
 #pragma unroll
             for (int g = 0; g < U; ++g) rw[q][g][0] = rw[q][g][1] = 0.0;
-        // Loads run three row steps ahead of their use (slot q of the queues: x row i+q, b row i-1+q at
-        // the step whose rotation is 0): with few waves per SIMD that is what keeps enough bytes in flight.
-        double xq[3][U][2], bq[3][U][2];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if constexpr (!ZERO) load_pairs(a.xin, i0 + q, xq[q]);
-            load_pairs(a.b, i0 - 1 + q, bq[q]);
-        }
-        // coarse rows for the prolongation: cA = row J, cB = row J+1 of the current fine row; cN and cM
-        // are the two rows after, as loaded (two to four steps before they become cB)
-        double cA0[U], cA1[U], cB0[U], cB1[U], cN0[U], cNe = 0, cM0[U], cMe = 0;
-        int Jh = 0;
-        if constexpr (PROLONG) {
-            Jh = (rowclamp(i0) - a.oj) >> 1;
-            double e0, e1;
-            load_coarse(Jh, cA0, e0);
-            load_coarse(Jh + 1, cB0, e1);
-            load_coarse(Jh + 2, cN0, cNe);
-            load_coarse(Jh + 3, cM0, cMe);
-            coarse_next(cA0, e0, cA1);
-            coarse_next(cB0, e1, cB1);
-        }
+        // Loads run three row steps ahead of their use: with few waves per SIMD that is what keeps
+        // enough bytes in flight.  bq[q]: b of row i-1+q at a step whose phase is a multiple of 3.
+        double bq[3][U][2];
+        // coarse rows for the prolongation: a ring of three rows that advances every other step, at
+        // compile-time phases (the loop starts on a row that is even relative to the coarse grid);
+        // C0 = value at coarse column c0/2, C1 = at the next column, Ce = the value beyond the strip
+        // (lane 63 only)
+        double C0[3][U], C1[3][U], Ce[3] = {0, 0, 0};
         const int oj = a.oj;
         const double h2 = a.h2, hh = a.hh;
 
         // PL: no Dirichlet cell, no clamped row or column in anything this wave streams.
         auto run = [&](auto plain_c) {
             constexpr bool PL = decltype(plain_c)::value;
+            // first row streamed; the coarse schedule wants it even relative to the coarse grid (one
+            // more row of lead-in, whose values nothing valid depends on)
+            const int ia = PROLONG ? i0 - ((i0 - oj) & 1) : i0;
+            if constexpr (PROLONG) { // before the row loads: the loop's first wait is for these
+                const int J = (ia - oj) >> 1;
+                load_coarse(J, C0[0], Ce[0]);
+                load_coarse(J + 1, C0[1], Ce[1]);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if constexpr (!ZERO) load_pairs(a.xin, ia + q, w[0][q]);
+                load_pairs(a.b, ia - 1 + q, bq[q]);
+            }
+            if constexpr (PROLONG) coarse_next(C0[0], Ce[0], C1[0]);
             // One row step.  R = rotation: this step's new rows go into slot R of every window; after
             // that the window's rows, oldest first, are slots A0, A1, A2.
-            auto step = [&](auto rot_c, const int i) {
-                constexpr int R = decltype(rot_c)::value;
+            auto step = [&](auto ph_c, const int i) {
+                constexpr int PH = decltype(ph_c)::value; // phase 0..5 of the unrolled loop
+                constexpr int R = PH % 3;
                 constexpr int A0 = (R + 1) % 3, A1 = (R + 2) % 3, A2 = R;
-                // ---- take the prefetched rows, issue the loads of the next step
+                // stage 0: row i sits in slot PH, rows i-1 and i-2 in the two slots before it, and the
+                // slot three ahead (row i-3, dead) takes the load of row i+3
+                constexpr int Z2 = PH, Z1 = (PH + 5) % 6, Z0 = (PH + 4) % 6, ZL = (PH + 3) % 6;
                 double bcur[U][2];
 #pragma unroll
                 for (int g = 0; g < U; ++g) {
-                    w[0][A2][g][0] = ZERO ? 0.0 : xq[R][g][0], w[0][A2][g][1] = ZERO ? 0.0 : xq[R][g][1];
+                    if constexpr (ZERO) w[0][Z2][g][0] = w[0][Z2][g][1] = 0.0;
                     bcur[g][0] = bq[R][g][0], bcur[g][1] = bq[R][g][1];
                 }
-                if constexpr (!ZERO) load_pairs(a.xin, i + 3, xq[R]);
-                load_pairs(a.b, i + 2, bq[R]);
+                if constexpr (!ZERO) load_pairs(a.xin, i + 3, w[0][ZL]);
                 if constexpr (PROLONG) {
-                    const int ic_ = rowclamp(i);
-                    const int J = (ic_ - oj) >> 1;
-                    if (J != Jh) { // uniform: at most one coarse row further
-#pragma unroll
-                        for (int g = 0; g < U; ++g) cA0[g] = cB0[g], cA1[g] = cB1[g], cB0[g] = cN0[g];
-                        coarse_next(cB0, cNe, cB1);
-#pragma unroll
-                        for (int g = 0; g < U; ++g) cN0[g] = cM0[g];
-                        cNe = cMe;
-                        Jh = J;
-                        load_coarse(Jh + 3, cM0, cMe);
+                    // rows are even relative to the coarse grid at even phases (the loop starts on one);
+                    // rows outside the array follow the same schedule, their coarse rows are clamped
+                    // loads that nothing uses
+                    constexpr int M = PH / 2;
+                    constexpr int SA = M % 3, SB = (M + 1) % 3, SN = (M + 2) % 3;
+                    if constexpr ((PH & 1) == 0) {
+                        const int J = (i - oj) >> 1;
+                        coarse_next(C0[SB], Ce[SB], C1[SB]);
+                        load_coarse(J + 2, C0[SN], Ce[SN]); // becomes row J+1 two steps from now
                     }
                     if (PL || (i > flo && i < fhi && i >= 0 && i <= ny - 1)) {
-                        const bool odd = (ic_ - oj) & 1;
 #pragma unroll
                         for (int g = 0; g < U; ++g) {
                             double add0, add1;
-                            if (odd) {
-                                add0 = (cA0[g] + cB0[g]) / 2;
-                                add1 = (cB1[g] + cB0[g] + cA1[g] + cA0[g]) / 4;
+                            if constexpr ((PH & 1) == 1) {
+                                add0 = (C0[SA][g] + C0[SB][g]) / 2;
+                                add1 = (C1[SB][g] + C0[SB][g] + C1[SA][g] + C0[SA][g]) / 4;
                             } else {
-                                add0 = cA0[g];
-                                add1 = (cA0[g] + cA1[g]) / 2;
+                                add0 = C0[SA][g];
+                                add1 = (C0[SA][g] + C1[SA][g]) / 2;
                             }
-                            if (PL || ic[g][0]) w[0][A2][g][0] += add0;
-                            if (PL || ic[g][1]) w[0][A2][g][1] += add1;
+                            if (PL || ic[g][0]) w[0][Z2][g][0] += add0;
+                            if (PL || ic[g][1]) w[0][Z2][g][1] += add1;
                         }
                     }
                 }
@@ -314,21 +317,23 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                         if constexpr (BL) __builtin_amdgcn_sched_barrier(0);
                     }
                     double(&bs)[U][2] = bsq[s & 1];
+                    // the window this stage reads, oldest row first
+                    constexpr int Q0 = s == 1 ? Z0 : A0, Q1 = s == 1 ? Z1 : A1, Q2 = s == 1 ? Z2 : A2;
 #pragma unroll
                     for (int g = 0; g < U; ++g) {
-                        double west = from_prev0(w[s - 1][A1][g][1]);
-                        double east = from_next0(w[s - 1][A1][g][0]);
+                        double west = from_prev0(w[s - 1][Q1][g][1]);
+                        double east = from_next0(w[s - 1][Q1][g][0]);
                         if (g > 0) {
-                            const double t = lane_bcast(w[s - 1][A1][g > 0 ? g - 1 : 0][1], 63);
+                            const double t = lane_bcast(w[s - 1][Q1][g > 0 ? g - 1 : 0][1], 63);
                             west = lane == 0 ? t : west;
                         }
                         if (g + 1 < U) {
-                            const double t = lane_bcast(w[s - 1][A1][g + 1 < U ? g + 1 : 0][0], 0);
+                            const double t = lane_bcast(w[s - 1][Q1][g + 1 < U ? g + 1 : 0][0], 0);
                             east = isR ? t : east;
                         }
-                        const double c0v = w[s - 1][A1][g][0], c1v = w[s - 1][A1][g][1];
-                        const double j0v = 0.25 * (c1v + west + w[s - 1][A2][g][0] + w[s - 1][A0][g][0] - h2 * bs[g][0]);
-                        const double j1v = 0.25 * (east + c0v + w[s - 1][A2][g][1] + w[s - 1][A0][g][1] - h2 * bs[g][1]);
+                        const double c0v = w[s - 1][Q1][g][0], c1v = w[s - 1][Q1][g][1];
+                        const double j0v = 0.25 * (c1v + west + w[s - 1][Q2][g][0] + w[s - 1][Q0][g][0] - h2 * bs[g][0]);
+                        const double j1v = 0.25 * (east + c0v + w[s - 1][Q2][g][1] + w[s - 1][Q0][g][1] - h2 * bs[g][1]);
                         o[g][0] = (PL || (rint && ic[g][0])) ? j0v : c0v;
                         o[g][1] = (PL || (rint && ic[g][1])) ? j1v : c1v;
                     }
@@ -344,6 +349,10 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                     }
                 };
                 stage(int_c<1>{});
+                // b of row i-1 has had its last use from the register: its slot takes the load of row i+2
+                // (issued here, not earlier, so that the old and the new value never coexist)
+                __builtin_amdgcn_sched_barrier(0);
+                load_pairs(a.b, i + 2, bq[R]);
                 if constexpr (K >= 2) stage(int_c<2>{});
                 if constexpr (K >= 3) stage(int_c<3>{});
                 if constexpr (K >= 4) stage(int_c<4>{});
@@ -437,20 +446,33 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                     }
                 }
             };
-            int i = i0;
-            for (; i + 3 <= i1; i += 3) {
-                step(int_c<0>{}, i);
-                step(int_c<1>{}, i + 1);
-                step(int_c<2>{}, i + 2);
-                if constexpr (BL) { // the oldest group becomes the youngest
+            int i = ia;
+            auto next_group = [&]() { // the oldest group of the b ring becomes the youngest
+                if constexpr (BL) {
                     double *const t = G[NG - 1];
 #pragma unroll
                     for (int k = NG - 1; k > 0; --k) G[k] = G[k - 1];
                     G[0] = t;
                 }
+            };
+            for (; i + 6 <= i1; i += 6) {
+                step(int_c<0>{}, i);
+                step(int_c<1>{}, i + 1);
+                step(int_c<2>{}, i + 2);
+                next_group();
+                step(int_c<3>{}, i + 3);
+                step(int_c<4>{}, i + 4);
+                step(int_c<5>{}, i + 5);
+                next_group();
             }
             if (i < i1) step(int_c<0>{}, i);
             if (i + 1 < i1) step(int_c<1>{}, i + 1);
+            if (i + 2 < i1) step(int_c<2>{}, i + 2);
+            if (i + 3 < i1) {
+                next_group();
+                step(int_c<3>{}, i + 3);
+                if (i + 4 < i1) step(int_c<4>{}, i + 4);
+            }
         };
         const bool plain = origin >= 1 && origin + W - 1 <= nx - 2 && origin + W <= ld && i0 - 1 > flo && i1 < fhi &&
                            i0 - 1 >= 0 && i1 <= ny - 1;
