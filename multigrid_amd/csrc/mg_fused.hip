@@ -225,6 +225,21 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                 load_pairs(a.b, ia - 1 + q, bq[q]);
             }
             if constexpr (PROLONG) coarse_next(C0[0], Ce[0], C1[0]);
+            // plain path: every row streamed lies inside the array, so the row pointers simply advance
+            const double *px = ZERO ? nullptr : a.xin + (i64)(ia + 3) * ld; // next x row to load
+            const double *pb = a.b + (i64)(ia + 2) * ld;                    // next b row to load
+            auto load_next = [&](const double *&ptr, int j, const double *base, double (&d)[U][2]) {
+                if constexpr (PL) {
+#pragma unroll
+                    for (int g = 0; g < U; ++g) {
+                        double2 t = *reinterpret_cast<const double2 *>(ptr + cl[g]);
+                        d[g][0] = t.x, d[g][1] = t.y;
+                    }
+                    ptr += ld;
+                } else {
+                    load_pairs(base, j, d);
+                }
+            };
             // One row step.  R = rotation: this step's new rows go into slot R of every window; after
             // that the window's rows, oldest first, are slots A0, A1, A2.
             auto step = [&](auto ph_c, const int i) {
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                     if constexpr (ZERO) w[0][Z2][g][0] = w[0][Z2][g][1] = 0.0;
                     bcur[g][0] = bq[R][g][0], bcur[g][1] = bq[R][g][1];
                 }
-                if constexpr (!ZERO) load_pairs(a.xin, i + 3, w[0][ZL]);
+                if constexpr (!ZERO) load_next(px, i + 3, a.xin, w[0][ZL]);
                 if constexpr (PROLONG) {
                     // rows are even relative to the coarse grid at even phases (the loop starts on one);
                     // rows outside the array follow the same schedule, their coarse rows are clamped
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                 // b of row i-1 has had its last use from the register: its slot takes the load of row i+2
                 // (issued here, not earlier, so that the old and the new value never coexist)
                 __builtin_amdgcn_sched_barrier(0);
-                load_pairs(a.b, i + 2, bq[R]);
+                load_next(pb, i + 2, a.b, bq[R]);
                 if constexpr (K >= 2) stage(int_c<2>{});
                 if constexpr (K >= 3) stage(int_c<3>{});
                 if constexpr (K >= 4) stage(int_c<4>{});
@@ -474,8 +489,9 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                 if (i + 4 < i1) step(int_c<4>{}, i + 4);
             }
         };
-        const bool plain = origin >= 1 && origin + W - 1 <= nx - 2 && origin + W <= ld && i0 - 1 > flo && i1 < fhi &&
-                           i0 - 1 >= 0 && i1 <= ny - 1;
+        // (the loop may start one row early and loads run three rows ahead)
+        const bool plain = origin >= 1 && origin + W - 1 <= nx - 2 && origin + W <= ld && i0 - 2 > flo && i1 < fhi &&
+                           i0 - 2 >= 0 && i1 + 2 <= ny - 1;
         if (plain)
             run(std::true_type{});
         else
