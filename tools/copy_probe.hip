@@ -28,6 +28,16 @@ __global__ __launch_bounds__(256) void add_gs(const double2* __restrict__ a, con
     double2 x = a[i], y = b[i]; o[i] = make_double2(x.x + y.x, x.y + y.y);
   }
 }
+// read-only: what the read side alone can stream (one double per block is written)
+__global__ __launch_bounds__(256) void read_gs(const double2* __restrict__ a, double* __restrict__ o, i64 n2) {
+  double acc = 0;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n2; i += (i64)gridDim.x * 256) { double2 x = a[i]; acc += x.x + x.y; }
+  if (acc == 12345.678) o[blockIdx.x] = acc;  // never true for the fill pattern; keeps the loads alive
+}
+// write-only
+__global__ __launch_bounds__(256) void fill_gs(double2* __restrict__ o, i64 n2) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n2; i += (i64)gridDim.x * 256) o[i] = make_double2(1.0, 2.0);
+}
 // column strips: block = 512 columns x rpb rows, marching down rows (like the stencil kernels)
 __global__ __launch_bounds__(256) void add_tile(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o,
                                                 i64 ld, int rpb, int ncb) {
@@ -66,6 +76,12 @@ int main(int argc, char** argv) {
   for (int blocks : {2048, 8192})  {
     char nm[64]; snprintf(nm, 64, "add_gs (2R1W) blocks=%d", blocks);
     report(nm, 3.0 * n * 8, [&] { hipLaunchKernelGGL(add_gs, dim3(blocks), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (double2*)o, n2); });
+  }
+  for (int blocks : {8192, 65536}) {
+    char nm[64]; snprintf(nm, 64, "read_gs (1R) blocks=%d", blocks);
+    report(nm, 1.0 * n * 8, [&] { hipLaunchKernelGGL(read_gs, dim3(blocks), dim3(256), 0, 0, (const double2*)a, o, n2); });
+    snprintf(nm, 64, "fill_gs (1W) blocks=%d", blocks);
+    report(nm, 1.0 * n * 8, [&] { hipLaunchKernelGGL(fill_gs, dim3(blocks), dim3(256), 0, 0, (double2*)o, n2); });
   }
   for (int rpb : {32, 128, 512}) {
     char nm[64]; snprintf(nm, 64, "add_tile (2R1W) rpb=%d", rpb);
