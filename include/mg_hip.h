@@ -43,6 +43,7 @@ const char *mg_last_error(void);
  *   "unroll"      1 | 2 | 4  accesses per lane and row
  *   "rows"        0..4096    rows per workgroup tile, 0 = automatic
  *   "linear_map"  0 | 1      1 disables the XCD-aware workgroup -> tile mapping
+ *   "fused_waves" 1 | 2 | 4  column strips (waves) per workgroup of the fused passes
  *   "sor_single_wave" 0|1|2  mg_sor, lexicographic: barrier-free one-wave kernel never / where it is
  *                            faster (default) / wherever the grid fits */
 int mg_set_tuning(const char *key, int value);

@@ -96,11 +96,12 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
     constexpr bool BL = D >= 5;                         // b ring in LDS
     constexpr int NG = BL ? (D + 1) / 3 + 1 : 1;        // groups of three row slots: rows i-1 .. i-D plus the rotation slack
     static_assert(K <= 6, "stages are instantiated up to 6 sweeps");
-    __shared__ double bring[BL ? 4 * NG * 3 * W : 1];
+    extern __shared__ double bring[]; // BL: (waves per workgroup) x NG x 3 row slots of W doubles
+    const int wpb = blockDim.x >> 6;
     int cb, rc;
     mg_tile_of_block((int)blockIdx.x, a.ncb, a.nrc, cb, rc);
     const int lane = threadIdx.x & 63;
-    const int tile = cb * 4 + (threadIdx.x >> 6);
+    const int tile = cb * wpb + (threadIdx.x >> 6);
     const bool active = tile < a.ntc;
     const int origin = (active ? tile : 0) * STRIDE;
     const int nx = (int)a.nx, ny = (int)a.ny, cnx = (int)a.cnx, cny = (int)a.cny;
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
             __syncthreads();
             if (threadIdx.x == 0) {
                 u64 m = wmax[0];
-                for (int k = 1; k < 4; ++k) m = wmax[k] > m ? wmax[k] : m;
+                for (int k = 1; k < wpb; ++k) m = wmax[k] > m ? wmax[k] : m;
                 if (m) atomicMax(&a.norm[blockIdx.x % MG_NORM_SLOTS], m);
             }
         }
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
 
 // ------------------------------------------------------------------------------------------ host
 
+int g_fused_waves = 4; // waves (column strips) per workgroup: tuning knob "fused_waves"
 static int g_fused_unroll = 2;
 static int g_fused_rows = 0;
 
@@ -530,8 +532,10 @@ template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
 static int launch_fused(FusedArgs a, hipStream_t st)
 {
     constexpr int D = K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0), Dv = (D + 1) & ~1, W = 128 * U, STRIDE = W - 2 * Dv;
+    constexpr int DK = K + (RESID ? 1 : 0); // window stages of the kernel: decides whether b lives in an LDS ring
     a.ntc = a.nx <= W ? 1 : (int)((a.nx - W + STRIDE - 1) / STRIDE) + 1;
-    a.ncb = (a.ntc + 3) / 4;
+    const int wpb = g_fused_waves;
+    a.ncb = (a.ntc + wpb - 1) / wpb;
     int rpb = g_fused_rows;
     if (rpb <= 0) {
         // measured at 32769 x 32769 (profiles/): 64-row tiles are as fast as or faster than taller ones at
@@ -542,7 +546,8 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     a.rpb = rpb;
     a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
     hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U>),
-                       dim3((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), dim3(256), 0, st, a);
+                       dim3((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), dim3(64 * wpb),
+                       DK >= 5 ? (size_t)wpb * ((DK + 1) / 3 + 1) * 3 * W * sizeof(double) : 0, st, a);
     MG_LAUNCH_CHECK("mg_smooth_fused");
     return 0;
 }

@@ -218,6 +218,7 @@ static int g_unroll = 2;    // accesses per lane and row: 1, 2 or 4
 static int g_rows = 0;      // rows per tile, 0 = automatic
 static int g_linear_map = 0;
 extern int g_sor_single_wave; // mg_sor.hip
+extern int g_fused_waves;     // mg_fused.hip
 
 extern "C" int mg_set_tuning(const char *key, int value)
 {
@@ -233,6 +234,9 @@ extern "C" int mg_set_tuning(const char *key, int value)
         g_rows = value;
     } else if (!strcmp(key, "linear_map")) {
         g_linear_map = value != 0;
+    } else if (!strcmp(key, "fused_waves")) {
+        MG_REQUIRE(value == 1 || value == 2 || value == 4, "mg_set_tuning: fused_waves must be 1, 2 or 4");
+        g_fused_waves = value;
     } else if (!strcmp(key, "sor_single_wave")) {
         MG_REQUIRE(value >= 0 && value <= 2, "mg_set_tuning: sor_single_wave must be 0, 1 or 2");
         g_sor_single_wave = value;

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--rows", type=int, nargs="*", default=[128, 256, 512, 1024])
     ap.add_argument("--unroll", type=int, nargs="*", default=[1, 2])
+    ap.add_argument("--waves", type=int, nargs="*", default=[4], help="column strips (waves) per workgroup")
     ap.add_argument("--only", nargs="*", default=None, help="kernel names to time (default: all)")
     args = ap.parse_args()
     import torch
@@ -67,23 +68,24 @@ def main():
     }
     if args.only:
         kernels = {k: v for k, v in kernels.items() if k in args.only}
-    configs = list(itertools.product(args.unroll, args.rows))
+    configs = list(itertools.product(args.unroll, args.rows, args.waves))
     results = {}
     for rnd in range(args.rounds):
         for cfg in configs:
             _lib.check(lib.mg_set_fused_tuning(cfg[0], cfg[1]))
+            _lib.check(lib.mg_set_tuning(b"fused_waves", cfg[2]))
             for name, (_, _, fn) in kernels.items():
                 results.setdefault((cfg, name), []).append(timed(fn))
         print(f"round {rnd} done", flush=True)
     print(f"grid {N}x{N}; per kernel: median ms, TB/s of the pass's own compulsory bytes")
-    print(f"{'unr':>3} {'rows':>5} | " + " | ".join(f"{k:>14}" for k in kernels))  # noqa
+    print(f"{'unr':>3} {'rows':>5} {'wv':>2} | " + " | ".join(f"{k:>14}" for k in kernels))  # noqa
     for cfg in configs:
         row = []
         for name, (bpp, _, _) in kernels.items():
             ts = sorted(results[(cfg, name)])
             med = ts[len(ts) // 2]
             row.append(f"{med:6.2f} {bpp * pts / med / 1e9:6.2f}")
-        print(f"{cfg[0]:>3} {cfg[1]:>5} | " + " | ".join(f"{v:>14}" for v in row), flush=True)
+        print(f"{cfg[0]:>3} {cfg[1]:>5} {cfg[2]:>2} | " + " | ".join(f"{v:>14}" for v in row), flush=True)
 
 
 if __name__ == "__main__":
