@@ -480,12 +480,20 @@ def test_fused_pass_partial_rows(L):
 @pytest.mark.parametrize("shape", [(40, 121), (70, 249), (300, 257), (130, 1001), (600, 2051)], ids=str)
 @pytest.mark.parametrize("sweeps", [1, 3, 6])
 @pytest.mark.parametrize("mode", ["plain", "zero", "prolong"])
-@pytest.mark.parametrize("store_r", [True, False])
-def test_fused_restriction_equals_separate_kernels(L, shape, sweeps, mode, store_r):
+@pytest.mark.parametrize("store_r,waves", [(True, 4), (False, 4), (False, 2), (True, 1)])
+def test_fused_restriction_equals_separate_kernels(L, shape, sweeps, mode, store_r, waves):
     """mg_smooth_fused_restrict == mg_smooth_fused followed by mg_restrict, bit for bit, whether or
-    not the residual itself is stored."""
+    not the residual itself is stored, for every number of column strips per workgroup."""
     import ctypes as C
     import torch
+    L.check(L.lib().mg_set_tuning(b"fused_waves", waves))
+    try:
+        _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r)
+    finally:
+        L.check(L.lib().mg_set_tuning(b"fused_waves", 4))
+
+
+def _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r):
     ny, nx = shape
     rng = np.random.default_rng(ny + 7 * nx + sweeps)
     h = 0.3
