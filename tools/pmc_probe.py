@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=14)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--fused-rows", type=int, default=0, help="tile height of the fused passes (0 = automatic)")
     args = ap.parse_args()
     import torch
     from multigrid_amd.levels import make_plan
@@ -27,6 +28,9 @@ def main():
     plan = make_plan(N, N, 2, 1, 0, 1.0)
     L0, L1 = plan.levels[0], plan.levels[1]
     ops = HipOps()
+    if args.fused_rows:
+        from multigrid_amd import _lib
+        _lib.check(_lib.lib().mg_set_fused_tuning(2, args.fused_rows))
     x = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
     y = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
     b = torch.rand((L0.ny, L0.ld), dtype=torch.float64, device="cuda")
