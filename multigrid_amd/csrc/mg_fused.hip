@@ -1,23 +1,25 @@
 // Fused smoothing passes of the V-cycle on gfx950 (temporal blocking).
 //
 // One launch performs, on a whole level and in ONE pass over memory,
-//     [x += prolongation(coarse)]  ->  K Jacobi sweeps  ->  [residual (+ max-norm)]
-// so that x and b are read once and x (and r) written once for K sweeps, instead of once per
-// sweep: K = 3 with both ends fused moves 26-32 B per point where the separate kernels move
-// 90-96 B.  Results are bit-identical to the separate kernels: every point value is computed by
-// the same expression from the same operands, only earlier.
+//     [x += prolongation(coarse)] -> K Jacobi sweeps -> [residual (+ max-norm)] -> [restriction]
+// so that x and b are read once and x (and r, and the coarse right-hand side) written once for K
+// sweeps, instead of once per operation: the finest-level pass of the V-cycle (prolongation, 6
+// sweeps, residual, norm, restriction) moves 28 B per point where the separate kernels move 196.
+// Results are bit-identical to the separate kernels: every point value is computed by the same
+// expression from the same operands, only earlier.
 //
 // How: a wave owns a strip of W = 128*U columns and streams down the rows.  It keeps, per stage
 // s = 0..D-1 (D = K, +1 with the residual), a three-row register window of stage-s values; when
 // input row i arrives, stage 1 can produce row i-1, stage 2 row i-2, ... stage K row i-K, the
-// residual row i-K-1.  Sideways, the values a stage needs from the neighbouring lane come by DPP
-// (v_readlane across the seam between a lane's column groups), and what lies beyond the strip is
-// simply not available: validity shrinks by one column per stage from both strip edges, so strips
-// overlap by 2*Dv columns (Dv = D rounded up to even, keeping every owned range aligned to the
-// 16-byte column pairs) and a strip stores only the columns it owns.  Dirichlet boundary cells are
-// passed through every stage unchanged, so validity does not shrink from a fixed boundary.
-// The same shrinking applies to rows: a tile producing rows [rb, re) streams rows rb-D .. re+D-1.
-// Redundant work: 2*Dv/W of the columns (3 % for D = 4, U = 2) and 2*D/rpb of the rows.
+// residual row i-K-1, the restriction the coarse row centred on row i-K-2.  Sideways, the values a
+// stage needs from the neighbouring lane come by DPP (v_readlane across the seam between a lane's
+// column groups), and what lies beyond the strip is simply not available: validity shrinks by one
+// column per stage from both strip edges, so strips overlap by 2*Dv columns (Dv = depth rounded up
+// to even, keeping every owned range aligned to the 16-byte column pairs) and a strip stores only
+// the columns it owns.  Dirichlet boundary cells are passed through every stage unchanged, so
+// validity does not shrink from a fixed boundary.  The same shrinking applies to rows: a tile
+// producing rows [rb, re) streams rows rb-depth .. re+depth-1.
+// Redundant work: 2*Dv/W of the columns and 2*depth/rpb of the rows.
 //
 // Arithmetic follows the reference's expression order (see include/mg_hip.h); compiled with
 // -ffp-contract=off.
@@ -67,13 +69,16 @@ __device__ __forceinline__ double from_next0(double v)
 template <int N>
 using int_c = std::integral_constant<int, N>;
 
-// The pass is bound by instruction issue as much as by memory (a row step of the 6-sweep pass with
-// residual and restriction needs ~110 FP64 operations and 32 lane shifts per wave), so the row loop
-// is written to add as little as possible to that:
-//  * the three-row windows are not shifted: the loop is unrolled by three and the slot a new row
-//    goes into rotates (step with rotation R overwrites slot R, the oldest row);
+// The deep passes run at 2-3 waves per SIMD, so instruction issue and exposed latency count as much
+// as memory (a row step of the 6-sweep pass with residual and restriction needs ~110 FP64 operations
+// and 32 lane shifts per wave).  The row loop is therefore fully static:
+//  * it is unrolled by six phases; windows are never shifted, the slot a new row goes into rotates;
+//  * nothing in flight is ever copied: stage 0 keeps a ring of six rows (its window plus the three
+//    rows being loaded ahead), b's queue slot is refilled after the row's last use, and the coarse
+//    rows of the prolongation advance at compile-time phases.  A register copy of a load's
+//    destination would wait for the whole in-order load queue and throw the prefetch away;
 //  * a wave whose strip and rows touch no Dirichlet cell and no array edge (almost all of them) runs
-//    a PLAIN instantiation without any of the per-cell selects;
+//    a PLAIN instantiation without any of the per-cell selects and with advancing row pointers;
 //  * row indices are 32-bit, so the uniform row tests are scalar compares.
 template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
 __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
