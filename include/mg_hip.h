@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 2
+#define MG_ABI_VERSION 3
 
 /* flags for the stencil entry points */
 #define MG_FLAG_FINEST 1 /* launch the instantiation named "...finest..." (profiler attribution only) */
@@ -134,17 +134,23 @@ int mg_prolong_add(const double *crs, int64_t cny, int64_t cnx, int64_t cld, dou
  * Needs 16-byte aligned arrays with an even ld.
   * Batches: nbatch grids, bstride elements apart in b/x_in/x_out/r (even), cstride in crs (and cbstride in
  * coarse_b below); one set of norm slots accumulates the max over all grids.
+  * prolong_after = 0: the prolongation comes before the first sweep (x_in required).  prolong_after = 3
+ * with sweeps = 9, x_in = NULL: a coarse level's whole smoothing in one pass -- 3 sweeps from x = 0
+ * (parallel_multigrid.py:276-277), += P(crs) (:309), 6 more sweeps (:310) -- so that the descent need not
+ * store x (mg_smooth_fused_restrict with x_out = NULL) and the ascent need not read it.
  */
 int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
                     int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld, int64_t j0,
-                    int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps, double h,
-                    uint64_t *norm_slots, int64_t nbatch, int64_t bstride, int64_t cstride, void *stream);
+                    int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps, int prolong_after,
+                    double h, uint64_t *norm_slots, int64_t nbatch, int64_t bstride, int64_t cstride,
+                    void *stream);
 /*
  * mg_smooth_fused with the full-weighting restriction of the residual fused in as a last stage:
  * coarse rows T0 <= T < T1 of coarse_b (cbny x cbnx, interior columns) are written as mg_restrict
  * (ofst_i = 0, the same ofst_j) would compute them from the residual; each coarse row's fine centre
  * row 2T + ofst_j must be one of the produced rows j0..j1-1.  r may be NULL: the residual is then
  * not stored at all (its Dirichlet cells count as 0, which is what a never-written r array holds).
+ * x_out may be NULL too: then only coarse_b (and the norm) come out of the pass.
  * Replaces the residual + exchange + coarse sequence of core/parallel_multigrid.py:114,:272-273,
  * :287-288.  Reads rows j0-D .. j1+D-1 with D = sweeps + 2.
  */

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 NORM_SLOTS = 64
 FLAG_FINEST = 1
 SOR_LEXICOGRAPHIC = 0
@@ -40,7 +40,7 @@ SIGNATURES = {
     "mg_maxabs": ([_p, _i, _i, _i, _p, _p], _n),
     "mg_restrict": ([_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _n),
     "mg_prolong_add": ([_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _n),
-    "mg_smooth_fused": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _d, _p, _i, _i, _i, _p], _n),
+    "mg_smooth_fused": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _n, _d, _p, _i, _i, _i, _p], _n),
     "mg_smooth_fused_restrict": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _d, _p, _p, _i, _i,
                                   _i, _i, _i, _i, _i, _i, _i, _p], _n),
     "mg_set_fused_tuning": ([_n, _n], _n),

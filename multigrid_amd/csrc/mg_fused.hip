@@ -80,13 +80,18 @@ using int_c = std::integral_constant<int, N>;
 //  * a wave whose strip and rows touch no Dirichlet cell and no array edge (almost all of them) runs
 //    a PLAIN instantiation without any of the per-cell selects and with advancing row pointers;
 //  * row indices are 32-bit, so the uniform row tests are scalar compares.
-template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
+// PS: the stage whose output row receives the prolongation.  0 = the input row, before the first
+// sweep (x += P(c), then K sweeps).  PS > 0 goes with ZERO: PS sweeps from x = 0, += P(c), K - PS
+// more sweeps -- a coarse level's pre-smoothing recomputed in front of its post-smoothing, so that
+// the descent need not store x and the ascent need not read it.
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0>
 __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
 {
     FusedArgs a = a0; // blockIdx.y = grid of the batch
     {
         const i64 g = blockIdx.y;
-        a.b += g * a.bstride, a.xout += g * a.bstride;
+        a.b += g * a.bstride;
+        if (a.xout) a.xout += g * a.bstride;
         if (a.xin) a.xin += g * a.bstride;
         if (a.r) a.r += g * a.bstride;
         if (a.crs) a.crs += g * a.cstride;
@@ -100,7 +105,9 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
     constexpr int STRIDE = W - 2 * Dv;
     constexpr bool BL = D >= 5;                         // b ring in LDS
     constexpr int NG = BL ? (D + 1) / 3 + 1 : 1;        // groups of three row slots: rows i-1 .. i-D plus the rotation slack
-    static_assert(K <= 6, "stages are instantiated up to 6 sweeps");
+    static_assert(K <= 9, "stages are instantiated up to 9 sweeps");
+    static_assert(PS == 0 || (PROLONG && ZERO && PS < K), "a prolongation inside the pipeline goes with a start from zero");
+    static_assert(!(PROLONG && ZERO) || PS > 0, "x = 0 + P(c) before the first sweep is not a mode of the cycle");
     extern __shared__ double bring[]; // BL: (waves per workgroup) x NG x 3 row slots of W doubles
     const int wpb = blockDim.x >> 6;
     int cb, rc;
@@ -219,9 +226,9 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
             constexpr bool PL = decltype(plain_c)::value;
             // first row streamed; the coarse schedule wants it even relative to the coarse grid (one
             // more row of lead-in, whose values nothing valid depends on)
-            const int ia = PROLONG ? i0 - ((i0 - oj) & 1) : i0;
+            const int ia = PROLONG ? i0 - ((i0 - PS - oj) & 1) : i0; // row ia - PS is the even one
             if constexpr (PROLONG) { // before the row loads: the loop's first wait is for these
-                const int J = (ia - oj) >> 1;
+                const int J = (ia - PS - oj) >> 1;
                 load_coarse(J, C0[0], Ce[0]);
                 load_coarse(J + 1, C0[1], Ce[1]);
             }
@@ -262,33 +269,36 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                     bcur[g][0] = bq[R][g][0], bcur[g][1] = bq[R][g][1];
                 }
                 if constexpr (!ZERO) load_next(px, i + 3, a.xin, w[0][ZL]);
-                if constexpr (PROLONG) {
-                    // rows are even relative to the coarse grid at even phases (the loop starts on one);
-                    // rows outside the array follow the same schedule, their coarse rows are clamped
-                    // loads that nothing uses
-                    constexpr int M = PH / 2;
-                    constexpr int SA = M % 3, SB = (M + 1) % 3, SN = (M + 2) % 3;
-                    if constexpr ((PH & 1) == 0) {
-                        const int J = (i - oj) >> 1;
-                        coarse_next(C0[SB], Ce[SB], C1[SB]);
-                        load_coarse(J + 2, C0[SN], Ce[SN]); // becomes row J+1 two steps from now
-                    }
-                    if (PL || (i > flo && i < fhi && i >= 0 && i <= ny - 1)) {
+                // Prolongation into row i - PS.  The loop starts on a step where that row is even
+                // relative to the coarse grid, so it is even at even phases; rows outside the array follow
+                // the same schedule, their coarse rows are clamped loads that nothing uses.
+                constexpr int PC = PH;
+                constexpr int CM = PC / 2;
+                constexpr int SA = CM % 3, SB = (CM + 1) % 3, SN = (CM + 2) % 3;
+                if constexpr (PROLONG && (PC & 1) == 0) {
+                    const int J = (i - PS - oj) >> 1;
+                    coarse_next(C0[SB], Ce[SB], C1[SB]);
+                    load_coarse(J + 2, C0[SN], Ce[SN]); // becomes row J+1 two steps from now
+                }
+                auto prolong_into = [&](double (&v)[U][2]) {
+                    const int rp = i - PS;
+                    if (PL || (rp > flo && rp < fhi && rp >= 0 && rp <= ny - 1)) {
 #pragma unroll
                         for (int g = 0; g < U; ++g) {
                             double add0, add1;
-                            if constexpr ((PH & 1) == 1) {
+                            if constexpr ((PC & 1) == 1) {
                                 add0 = (C0[SA][g] + C0[SB][g]) / 2;
                                 add1 = (C1[SB][g] + C0[SB][g] + C1[SA][g] + C0[SA][g]) / 4;
                             } else {
                                 add0 = C0[SA][g];
                                 add1 = (C0[SA][g] + C1[SA][g]) / 2;
                             }
-                            if (PL || ic[g][0]) w[0][Z2][g][0] += add0;
-                            if (PL || ic[g][1]) w[0][Z2][g][1] += add1;
+                            if (PL || ic[g][0]) v[g][0] += add0;
+                            if (PL || ic[g][1]) v[g][1] += add1;
                         }
                     }
-                }
+                };
+                if constexpr (PROLONG && PS == 0) prolong_into(w[0][Z2]);
                 // ---- push b (row i-1)
                 if constexpr (BL) {
 #pragma unroll
@@ -358,7 +368,8 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                         o[g][0] = (PL || (rint && ic[g][0])) ? j0v : c0v;
                         o[g][1] = (PL || (rint && ic[g][1])) ? j1v : c1v;
                     }
-                    if (s == K && row >= rb && row < re) {
+                    if constexpr (PROLONG && PS > 0 && s == PS) prolong_into(o);
+                    if (s == K && a.xout && row >= rb && row < re) {
                         double *orow = a.xout + (i64)row * ld;
 #pragma unroll
                         for (int g = 0; g < U; ++g)
@@ -379,6 +390,9 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                 if constexpr (K >= 4) stage(int_c<4>{});
                 if constexpr (K >= 5) stage(int_c<5>{});
                 if constexpr (K >= 6) stage(int_c<6>{});
+                if constexpr (K >= 7) stage(int_c<7>{});
+                if constexpr (K >= 8) stage(int_c<8>{});
+                if constexpr (K >= 9) stage(int_c<9>{});
                 // ---- residual of row i-K-1 from the stage-K window
                 if constexpr (RESID) {
                     const int row = i - K - 1;
@@ -533,7 +547,7 @@ extern "C" int mg_set_fused_tuning(int unroll, int rows)
     return 0;
 }
 
-template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U>
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0>
 static int launch_fused(FusedArgs a, hipStream_t st)
 {
     constexpr int D = K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0), Dv = (D + 1) & ~1, W = 128 * U, STRIDE = W - 2 * Dv;
@@ -550,7 +564,7 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     }
     a.rpb = rpb;
     a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
-    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U>),
+    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U, PS>),
                        dim3((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), dim3(64 * wpb),
                        DK >= 5 ? (size_t)wpb * ((DK + 1) / 3 + 1) * 3 * W * sizeof(double) : 0, st, a);
     MG_LAUNCH_CHECK("mg_smooth_fused");
@@ -586,26 +600,34 @@ static int pick_mode(const FusedArgs &a, bool prolong, bool zero, bool resid, bo
 
 static int smooth_fused_impl(const double *b, const double *x_in, double *x_out, double *r, const double *crs, i64 ny,
                              i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo, i64 fix_hi,
-                             i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, bool want_resid, double *coarse_b,
+                             i64 ofst_j, int sweeps, int prolong_after, double h, uint64_t *norm_slots, bool want_resid,
+                             double *coarse_b,
                              i64 cbny, i64 cbnx, i64 cbld, i64 T0, i64 T1, i64 nbatch, i64 bstride, i64 cstride,
                              i64 cbstride, void *stream)
 {
-    MG_REQUIRE(b && x_out, "mg_smooth_fused: null array");
+    MG_REQUIRE(b && (x_out || coarse_b), "mg_smooth_fused: null array");
     MG_REQUIRE(nbatch >= 1 && nbatch <= 65535, "mg_smooth_fused: nbatch %lld outside 1..65535", (long long)nbatch);
     MG_REQUIRE(nbatch == 1 || (bstride >= ny * ld && bstride % 2 == 0 && (!crs || cstride >= cny * cld) &&
                                (!coarse_b || cbstride >= cbny * cbld)),
                "mg_smooth_fused: batch strides overlap consecutive grids (or the fine stride is odd)");
-    MG_REQUIRE(sweeps >= 1 && sweeps <= 6, "mg_smooth_fused: 1..6 sweeps per pass, got %d", sweeps);
+    if (prolong_after > 0) {
+        // the one combination the V-cycle uses: N1 = 3 sweeps from zero, + P(c), N2 = 6 more sweeps
+        MG_REQUIRE(sweeps == 9 && prolong_after == 3 && !x_in && crs && !coarse_b && x_out,
+                   "mg_smooth_fused: prolong_after is implemented for 9 sweeps from x = 0 with the prolongation after 3");
+    } else {
+        MG_REQUIRE(sweeps >= 1 && sweeps <= 6, "mg_smooth_fused: 1..6 sweeps per pass, got %d", sweeps);
+    }
     MG_REQUIRE(ny >= 3 && nx >= 3 && ld >= nx, "mg_smooth_fused: bad shape");
-    MG_REQUIRE(ld % 2 == 0 && mg_aligned(b, 16) && mg_aligned(x_out, 16) && (!x_in || mg_aligned(x_in, 16)) &&
+    MG_REQUIRE(ld % 2 == 0 && mg_aligned(b, 16) && (!x_out || mg_aligned(x_out, 16)) && (!x_in || mg_aligned(x_in, 16)) &&
                    (!r || mg_aligned(r, 16)),
                "mg_smooth_fused: arrays must be 16-byte aligned with an even leading dimension");
     MG_REQUIRE(j0 >= 0 && j1 <= ny && j0 <= j1, "mg_smooth_fused: row range [%lld, %lld) outside the array", (long long)j0,
                (long long)j1);
-    MG_REQUIRE(x_in != x_out && r != x_out && (!r || (const double *)r != x_in), "mg_smooth_fused: aliased arrays");
+    MG_REQUIRE((!x_out || (x_in != x_out && r != x_out)) && (!r || (const double *)r != x_in),
+               "mg_smooth_fused: aliased arrays");
     MG_REQUIRE(nx < ((i64)1 << 30) && ny < ((i64)1 << 30), "mg_smooth_fused: grid side too large");
     if (crs) {
-        MG_REQUIRE(x_in, "mg_smooth_fused: prolongation needs x_in");
+        MG_REQUIRE(x_in || prolong_after > 0, "mg_smooth_fused: prolongation needs x_in");
         MG_REQUIRE(cny >= 2 && cnx >= 2 && cld >= cnx, "mg_smooth_fused: bad coarse shape");
         MG_REQUIRE(ofst_j <= 0, "mg_smooth_fused: ofst_j must be <= 0");
         // every fine cell of the produced rows must have its coarse cells: 1 <= t - ofst_j <= 2*cny-3,
@@ -641,6 +663,8 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
     const bool zero = x_in == nullptr, prolong = crs != nullptr, restr = coarse_b != nullptr;
     const bool resid = want_resid || restr;
     hipStream_t st = (hipStream_t)stream;
+    if (prolong_after > 0)
+        return resid ? launch_fused<9, true, true, true, false, 1, 3>(a, st) : launch_fused<9, true, true, false, false, 1, 3>(a, st);
     switch (sweeps) {
     case 1: return pick_mode<1>(a, prolong, zero, resid, restr, st);
     case 2: return pick_mode<2>(a, prolong, zero, resid, restr, st);
@@ -653,11 +677,12 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
 
 extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
                                i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo,
-                               i64 fix_hi, i64 ofst_j, int sweeps, double h, uint64_t *norm_slots, i64 nbatch,
-                               i64 bstride, i64 cstride, void *stream)
+                               i64 fix_hi, i64 ofst_j, int sweeps, int prolong_after, double h,
+                               uint64_t *norm_slots, i64 nbatch, i64 bstride, i64 cstride, void *stream)
 {
     return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
-                             h, norm_slots, r != nullptr, nullptr, 0, 0, 0, 0, 0, nbatch, bstride, cstride, 0, stream);
+                             prolong_after, h, norm_slots, r != nullptr, nullptr, 0, 0, 0, 0, 0, nbatch, bstride, cstride,
+                             0, stream);
 }
 
 extern "C" int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out, double *r,
@@ -668,6 +693,6 @@ extern "C" int mg_smooth_fused_restrict(const double *b, const double *x_in, dou
 {
     MG_REQUIRE(coarse_b, "mg_smooth_fused_restrict: null coarse array");
     return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
-                             h, norm_slots, true, coarse_b, cbny, cbnx, cbld, T0, T1, nbatch, bstride, cstride,
+                             0, h, norm_slots, true, coarse_b, cbny, cbnx, cbld, T0, T1, nbatch, bstride, cstride,
                              cbstride, stream);
 }

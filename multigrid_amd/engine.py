@@ -46,7 +46,7 @@ class SlabMultigrid:
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
-                 store_residual_every_cycle=False, batch=None, dist_min_rows=256):
+                 store_residual_every_cycle=False, batch=None, dist_min_rows=256, recompute_presmoothing=True):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -83,6 +83,10 @@ class SlabMultigrid:
         self.fix_coarse_ascent = fix_coarse_ascent
         self.keep_ascent_residuals = keep_ascent_residuals
         self.max_cycles = max_cycles
+        # On a level that is not cut into slabs the post-smoothing pass recomputes the pre-smoothing sweeps
+        # (from x = 0, 3 sweeps) in front of its own instead of reading their result: the descent pass then
+        # need not store x at all.  16 B per point less traffic on every coarse level, identical values.
+        self.recompute_presmoothing = recompute_presmoothing
         # With the reference's loop bounds nothing computed on the whole-domain levels below the first
         # ever reaches the solution (:302).  They are a pure function of rw[0], so unless asked to they
         # are not computed every cycle but on demand (sync_whole_levels), with identical values.
@@ -244,6 +248,17 @@ class SlabMultigrid:
         # where the restriction goes: the next level's b, or the slab that is then all-gathered into it
         Lc = self.plan.levels[l + 1] if to_rep else self.lv[l + 1]
         cb = self._bslab if to_rep else self.b[l + 1]
+        if self.fused and self._recomputed(l):
+            if src is None:  # descent: only the restricted residual leaves the pass
+                assert restrict and crs is None
+                o.smooth_fused(self.b[l], None, None, r, None, L.nx, cnx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, n, L.h,
+                               norm, cb, Lc.nx, Lc.t0, Lc.t1)
+                return None
+            # ascent: N1 sweeps from zero, + P(crs), the n post-smoothing sweeps
+            assert crs is not None and not restrict
+            o.smooth_fused(self.b[l], None, xa, r, crs, L.nx, cnx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, self.N1 + n, L.h,
+                           norm, prolong_after=self.N1)
+            return xa
         if self.fused:
             extra = (2 if restrict else 1 if r is not None else 0)
             chunks = self._chunks(n, min(6, L.halo - extra) if dist_ else 6)
@@ -296,6 +311,12 @@ class SlabMultigrid:
             if to_rep:
                 self._allgather_b(l + 1)
         return src
+
+    def _recomputed(self, l):
+        """Does level l run in the recompute scheme?  (Levels that are cut into slabs keep x between the
+        passes: recomputing would need a halo as deep as both smoothings together.)"""
+        return (self.recompute_presmoothing and self.fused and l >= 1 and (self.world == 1 or l >= self.n_dist)
+                and self.N1 == 3 and self.N2 == 6 and getattr(self.ops, "supports_prolong_after", False))
 
     def _allgather_b(self, lc):
         """Every rank's owned rows of the slab right-hand side of level lc -> the replicated b[lc]."""

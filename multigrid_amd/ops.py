@@ -135,22 +135,24 @@ class HipOps:
                                     nb, cbs, fbs, self._s))
 
     supports_fused = True
+    supports_prolong_after = True
 
     def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
-                     coarse_b=None, cbnx=0, T0=0, T1=0):
+                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0):
         """[x_in += P(crs)] -> `sweeps` Jacobi sweeps -> [residual] -> [restriction into coarse_b];
-        x_in None = start from zero."""
+        x_in None = start from zero; x_out None (with coarse_b) = x is not stored; prolong_after = n:
+        the prolongation is added after the first n sweeps (from zero) instead of before the first."""
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         self._same_layout(b, x_in, x_out, r)
-        nb, bs, ny, ld = self._nb(x_out)
+        nb, bs, ny, ld = self._nb(b)
         _, cs, cny, cld = self._nb(crs) if crs is not None else (1, 0, 0, 0)
-        common = (p(b), p(x_in), p(x_out), p(r), p(crs), ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, oj, sweeps,
-                  h, p(norm))
+        common = (p(b), p(x_in), p(x_out), p(r), p(crs), ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, oj, sweeps)
         if coarse_b is None:
-            check(self.L.mg_smooth_fused(*common, nb, bs, cs, self._s))
+            check(self.L.mg_smooth_fused(*common, prolong_after, h, p(norm), nb, bs, cs, self._s))
         else:
             _, cbs, cbny, cbld = self._nb(coarse_b)
-            check(self.L.mg_smooth_fused_restrict(*common, p(coarse_b), cbny, cbnx, cbld, T0, T1, nb, bs, cs, cbs,
+            assert prolong_after == 0
+            check(self.L.mg_smooth_fused_restrict(*common, h, p(norm), p(coarse_b), cbny, cbnx, cbld, T0, T1, nb, bs, cs, cbs,
                                                   self._s))
 
     def sor(self, b, x, r, nx, h, iterations, ordering):

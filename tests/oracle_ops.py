@@ -119,27 +119,34 @@ class OracleOps:
         f.numpy()[t0:t1, 1 : fnx - 1] = fc[t0:t1, 1 : fnx - 1]
 
     supports_fused = True
+    supports_prolong_after = True
 
     @_batched
     def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
-                     coarse_b=None, cbnx=0, T0=0, T1=0):
-        """The fused pass as the sequence it stands for: prolong_add, `sweeps` Jacobi sweeps, residual
-        (rows between the fixed rows are the interior; only rows j0..j1-1 are written back)."""
-        ny = x_out.shape[0]
+                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0):
+        """The fused pass as the sequence it stands for: prolong_add (before the first sweep, or after
+        `prolong_after` sweeps from zero), `sweeps` Jacobi sweeps, residual (rows between the fixed rows
+        are the interior; only rows j0..j1-1 are written back)."""
+        ny = b.shape[0]
         lo, hi = max(fix_lo + 1, 1), min(fix_hi, ny - 1)  # rows a sweep may update; what lies beyond a
-        cur = torch.zeros_like(x_out) if x_in is None else x_in.clone()  # non-fixed end is halo
-        if crs is not None:
-            self.prolong_add(crs, cnx, cur, nx, max(fix_lo + 1, 0), min(fix_hi, ny), 0, oj)
-        for _ in range(sweeps):
+        cur = torch.zeros_like(b) if x_in is None else x_in.clone()  # non-fixed end is halo
+        if prolong_after:
+            assert x_in is None and crs is not None
+        for k in range(sweeps + 1):
+            if crs is not None and k == prolong_after:
+                self.prolong_add(crs, cnx, cur, nx, max(fix_lo + 1, 0), min(fix_hi, ny), 0, oj)
+            if k == sweeps:
+                break
             nxt = cur.clone()
             self.jacobi(b, cur, nxt, nx, lo, hi, h)
             cur = nxt
-        x_out[j0:j1] = cur[j0:j1]
+        if x_out is not None:
+            x_out[j0:j1] = cur[j0:j1]
         if r is not None:
             self.residual(r, cur, b, nx, j0, j1, h, norm)
         if coarse_b is not None:
             # the residual on every row a sweep may touch (halo rows included), Dirichlet cells as r holds them
-            rt = r.clone() if r is not None else torch.zeros_like(x_out)
+            rt = r.clone() if r is not None else torch.zeros_like(b)
             self.residual(rt, cur, b, nx, lo, hi, h, norm if r is None else None)
             self.restrict(rt, nx, coarse_b, cbnx, T0, T1, 0, oj)
 

@@ -444,7 +444,7 @@ def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unrol
     L.check(lib.mg_smooth_fused(db.data_ptr(), None if mode == "zero" else dx.data_ptr(), out.data_ptr(),
                                 rr.data_ptr() if resid else None, dc.data_ptr() if prolong else None, ny, nx, ld,
                                 cny if prolong else 0, cnx if prolong else 0, dc.stride(0) if prolong else 0, j0, j1,
-                                flo, fhi, -1, sweeps, h, slots.data_ptr() if resid else None, 1, 0, 0, st))
+                                flo, fhi, -1, sweeps, 0, h, slots.data_ptr() if resid else None, 1, 0, 0, st))
     assert np.array_equal(out.cpu().numpy(), cur.cpu().numpy())
     if resid:
         nrm = C.c_double()
@@ -470,7 +470,7 @@ def test_fused_pass_partial_rows(L):
         cur, oth = oth, cur
     out = padded(np.full((ny, nx), 5.0))
     L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), out.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, 60, 131, 0,
-                                ny - 1, 0, 3, h, None, 1, 0, 0, st))
+                                ny - 1, 0, 3, 0, h, None, 1, 0, 0, st))
     got, ref = out.cpu().numpy(), cur.cpu().numpy()
     assert np.array_equal(got[60:131], ref[60:131])
     got[60:131] = 5.0
@@ -515,17 +515,17 @@ def _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r):
     zc = np.zeros((cny, cnx))
     args = (db.data_ptr(), None if mode == "zero" else dx.data_ptr())
     cargs = (dc.data_ptr() if c is not None else None, ny, nx, ld, cny if c is not None else 0,
-             cnx if c is not None else 0, dc.stride(0) if c is not None else 0, j0, j1, flo, fhi, -1, sweeps, h)
+             cnx if c is not None else 0, dc.stride(0) if c is not None else 0, j0, j1, flo, fhi, -1, sweeps)
     # separate: fused smoothing + residual, then the restriction kernel
     o1, r1, cb1 = padded(x), padded(z), padded(zc)
     s1 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
-    L.check(lib.mg_smooth_fused(*args, o1.data_ptr(), r1.data_ptr(), *cargs, s1.data_ptr(), 1, 0, 0, st))
+    L.check(lib.mg_smooth_fused(*args, o1.data_ptr(), r1.data_ptr(), *cargs, 0, h, s1.data_ptr(), 1, 0, 0, st))
     L.check(lib.mg_restrict(r1.data_ptr(), ny, nx, ld, cb1.data_ptr(), cny, cnx, cb1.stride(0), 2, cny - 1, 0, -1, 1, 0, 0,
                             st))
     # fused
     o2, r2, cb2 = padded(x), padded(z), padded(zc)
     s2 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
-    L.check(lib.mg_smooth_fused_restrict(*args, o2.data_ptr(), r2.data_ptr() if store_r else None, *cargs, s2.data_ptr(),
+    L.check(lib.mg_smooth_fused_restrict(*args, o2.data_ptr(), r2.data_ptr() if store_r else None, *cargs, h, s2.data_ptr(),
                                          cb2.data_ptr(), cny, cnx, cb2.stride(0), 2, cny - 1, 1, 0, 0, 0, st))
     assert np.array_equal(o2.cpu().numpy(), o1.cpu().numpy())
     assert np.array_equal(cb2.cpu().numpy(), cb1.cpu().numpy())
@@ -537,3 +537,67 @@ def _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r):
         assert np.array_equal(r2.cpu().numpy(), r1.cpu().numpy())
     else:
         assert not r2.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("shape", [(10, 9), (18, 17), (34, 33), (40, 121), (70, 249), (300, 257), (130, 1001), (600, 2051),
+                                   (258, 4099)], ids=str)
+@pytest.mark.parametrize("resid", [False, True])
+def test_fused_presmoothing_recomputed(L, shape, resid):
+    """prolong_after = 3, sweeps = 9: 3 sweeps from x = 0, += P(c), 6 sweeps [, residual] in one pass ==
+    the separate kernels; and the descent pass that stores no x produces the same coarse right-hand
+    side and norm as the one that does."""
+    import ctypes as C
+    import torch
+    ny, nx = shape
+    rng = np.random.default_rng(ny + 3 * nx)
+    h = 0.3
+    b = rng.standard_normal(shape)
+    flo, fhi, j0, j1 = 1, ny - 1, 2, ny - 1
+    R = ny - 2
+    assert R % 2 == 0 and nx % 2 == 1
+    cny, cnx = R // 2 + 2, (nx - 1) // 2 + 1
+    c = rng.standard_normal((cny, cnx))
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    db, dc = padded(b), padded(c)
+    ld = db.stride(0)
+    z = np.zeros(shape)
+    cur, oth = padded(z), padded(z)
+    for k in range(9):
+        if k == 3:
+            L.check(lib.mg_prolong_add(dc.data_ptr(), cny, cnx, dc.stride(0), cur.data_ptr(), ny, nx, ld, j0, j1, 1, nx - 2,
+                                       0, -1, 1, 0, 0, st))
+            oth.copy_(cur)
+        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, j0, j1, h, 1, 0, 0, st))
+        cur, oth = oth, cur
+    r_ref = padded(z)
+    s1 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
+    if resid:
+        L.check(lib.mg_residual(r_ref.data_ptr(), cur.data_ptr(), db.data_ptr(), ny, nx, ld, j0, j1, h, s1.data_ptr(), 1, 0, 0,
+                                st))
+    out, rr = padded(z), padded(z)
+    s2 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
+    L.check(lib.mg_smooth_fused(db.data_ptr(), None, out.data_ptr(), rr.data_ptr() if resid else None, dc.data_ptr(), ny, nx,
+                                ld, cny, cnx, dc.stride(0), j0, j1, flo, fhi, -1, 9, 3, h, s2.data_ptr() if resid else None,
+                                1, 0, 0, st))
+    assert np.array_equal(out.cpu().numpy(), cur.cpu().numpy())
+    if resid:
+        assert np.array_equal(rr.cpu().numpy(), r_ref.cpu().numpy())
+        n1, n2 = C.c_double(), C.c_double()
+        L.check(lib.mg_norm_read(s1.data_ptr(), C.byref(n1), st))
+        L.check(lib.mg_norm_read(s2.data_ptr(), C.byref(n2), st))
+        assert n1.value == n2.value
+    # descent pass with and without the x output
+    zc = np.zeros((cny, cnx))
+    o1, cb1, cb2 = padded(z), padded(zc), padded(zc)
+    for xo, cb in ((o1, cb1), (None, cb2)):
+        L.check(lib.mg_smooth_fused_restrict(db.data_ptr(), None, xo.data_ptr() if xo is not None else None, None, None, ny,
+                                             nx, ld, 0, 0, 0, j0, j1, flo, fhi, -1, 3, h, None, cb.data_ptr(), cny, cnx,
+                                             cb.stride(0), 2, cny - 1, 1, 0, 0, 0, st))
+    assert np.array_equal(cb1.cpu().numpy(), cb2.cpu().numpy())
+    assert cb1.cpu().numpy().any()
+    # rejected combinations
+    assert lib.mg_smooth_fused(db.data_ptr(), None, out.data_ptr(), None, dc.data_ptr(), ny, nx, ld, cny, cnx, dc.stride(0),
+                               j0, j1, flo, fhi, -1, 6, 3, h, None, 1, 0, 0, st) != 0
+    assert lib.mg_smooth_fused(db.data_ptr(), out.data_ptr(), rr.data_ptr(), None, dc.data_ptr(), ny, nx, ld, cny, cnx,
+                               dc.stride(0), j0, j1, flo, fhi, -1, 9, 3, h, None, 1, 0, 0, st) != 0
