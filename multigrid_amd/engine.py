@@ -46,7 +46,8 @@ class SlabMultigrid:
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
-                 store_residual_every_cycle=False, batch=None, dist_min_rows=256, recompute_presmoothing=True):
+                 store_residual_every_cycle=False, batch=None, dist_min_rows=256, recompute_presmoothing=True,
+                 recompute_min_nx=1024, recompute_min_blocks=1024):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -87,6 +88,7 @@ class SlabMultigrid:
         # (from x = 0, 3 sweeps) in front of its own instead of reading their result: the descent pass then
         # need not store x at all.  16 B per point less traffic on every coarse level, identical values.
         self.recompute_presmoothing = recompute_presmoothing
+        self.recompute_min_nx, self.recompute_min_blocks = recompute_min_nx, recompute_min_blocks
         # With the reference's loop bounds nothing computed on the whole-domain levels below the first
         # ever reaches the solution (:302).  They are a pure function of rw[0], so unless asked to they
         # are not computed every cycle but on demand (sync_whole_levels), with identical values.
@@ -315,8 +317,15 @@ class SlabMultigrid:
     def _recomputed(self, l):
         """Does level l run in the recompute scheme?  (Levels that are cut into slabs keep x between the
         passes: recomputing would need a halo as deep as both smoothings together.)"""
-        return (self.recompute_presmoothing and self.fused and l >= 1 and (self.world == 1 or l >= self.n_dist)
-                and self.N1 == 3 and self.N2 == 6 and getattr(self.ops, "supports_prolong_after", False))
+        if not (self.recompute_presmoothing and self.fused and l >= 1 and (self.world == 1 or l >= self.n_dist)
+                and self.N1 == 3 and self.N2 == 6 and getattr(self.ops, "supports_prolong_after", False)):
+            return False
+        # The 9-deep pass pays with wider overlaps (20 of 128 columns, 18 rows per tile end), which a
+        # level must be wide enough and have workgroups enough to absorb (measured: it wins from
+        # 8193 x 8193 on, loses at 4097 x 4097 and on batches of narrow grids).
+        L = self.lv[l]
+        blocks = -(-(-(-L.nx // 108)) // 4) * -(-L.rows // 64) * (self.batch or 1)
+        return L.nx >= self.recompute_min_nx and blocks >= self.recompute_min_blocks
 
     def _allgather_b(self, lc):
         """Every rank's owned rows of the slab right-hand side of level lc -> the replicated b[lc]."""

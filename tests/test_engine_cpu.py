@@ -29,6 +29,8 @@ def _rhs(gny, gnx, seed=0):
 
 def _engine_run(gny, gnx, n_para, h, b, world, rank, cycles, group=None, **kw):
     """b: global right-hand side; every rank takes its rows."""
+    kw.setdefault("recompute_min_nx", 0)      # exercise the recompute scheme at these small sizes too
+    kw.setdefault("recompute_min_blocks", 0)
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, ops=OracleOps(), world=world, rank=rank, group=group, **kw)
     R = eng.plan.levels[0].rows
     a, e = eng.owned_rows()

@@ -49,14 +49,17 @@ CASES = [(65, 65, 2), (129, 129, 3), (65, 129, 3), (257, 33, 2), (33, 33, 1), (1
 
 @pytest.mark.parametrize("gny,gnx,n_para", CASES, ids=str)
 @pytest.mark.parametrize("ordering", ["lexicographic", "redblack"])
-@pytest.mark.parametrize("graph", [True, False])
-def test_engine_equals_global_oracle(gny, gnx, n_para, ordering, graph):
+@pytest.mark.parametrize("graph,recompute", [(True, True), (False, True), (True, False)])
+def test_engine_equals_global_oracle(gny, gnx, n_para, ordering, graph, recompute):
     b = _rhs(gny, gnx)
     h = 0.37
     ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0, ordering)
     ref.b[:] = b
     ref.solve(ncycles=4)
-    eng = _make(gny, gnx, n_para, h, 0.0, b, coarse_ordering=ordering, use_graph=graph)
+    # recompute: the coarse levels' post-smoothing passes recompute the pre-smoothing (forced here: by
+    # default only large levels do)
+    eng = _make(gny, gnx, n_para, h, 0.0, b, coarse_ordering=ordering, use_graph=graph, recompute_presmoothing=recompute,
+                recompute_min_nx=0, recompute_min_blocks=0)
     eng.presmooth()
     errs = eng.cycles(4)
     assert errs == ref.err_hist.tolist()
@@ -107,7 +110,8 @@ def test_batch_of_problems_equals_independent_solves(B, N, n_para, graph):
         ref.b[:] = bs[k]
         ref.solve(ncycles=3)
         refs.append(ref)
-    eng = SlabMultigrid(N, N, n_para, h, 0.0, world=1, rank=0, batch=B, use_graph=graph, eager_dead_levels=True)
+    eng = SlabMultigrid(N, N, n_para, h, 0.0, world=1, rank=0, batch=B, use_graph=graph, eager_dead_levels=True,
+                        recompute_min_nx=0 if graph else 1024, recompute_min_blocks=0 if graph else 1024)
     eng.set_b_rows(torch.from_numpy(bs).cuda())
     eng.presmooth()
     errs = eng.cycles(3)

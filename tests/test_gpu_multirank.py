@@ -31,7 +31,7 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_mi
         from multigrid_amd.engine import SlabMultigrid
         # dead whole-domain levels every cycle for the larger grids: rank 0 runs them as a graph on a side stream
         eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank, fused=fused, eager_dead_levels=gny > 300,
-                            dist_min_rows=dist_min_rows)
+                            dist_min_rows=dist_min_rows, recompute_min_nx=0, recompute_min_blocks=0)
         assert eng.comm.staged
         R = eng.plan.levels[0].rows
         a, e = eng.owned_rows()
