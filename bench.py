@@ -232,7 +232,7 @@ def main():
         pass_ms = timed(lambda k: ops.smooth_fused(eng.b[0], xs[k & 1], xs[1 - (k & 1)], None, crs, L0.nx, L1.nx,
                                                    L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, L0.h, eng.norm,
                                                    eng.b[1], L1.nx, L1.t0, L1.t1))
-        dom_name = ("mg_fused_kernel<6, true, false, true, true, 1> (finest level: prolongation + 6 Jacobi sweeps + "
+        dom_name = ("mg_fused_kernel<6, true, false, true, true, 1, 0> (finest level: prolongation + 6 Jacobi sweeps + "
                     "residual + max-norm + restriction)")
         dom_ms = pass_ms
         alg_bpp = 18 + 6 * 24 + 24 + 10  # per-operation compulsory bytes x the operations this launch performs

@@ -49,11 +49,14 @@ def main():
         ops.smooth_fused(b, x, y, r, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, 0.5, slots)
         ops.smooth_fused(b, None, y, r, None, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 3, 0.5, None)
         ops.smooth_fused(b, x, y, None, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, 0.5, None)
-        # the two passes the cycle runs with the restriction fused in (finest level; descent of a coarser one)
+        # the finest-level pass of the cycle, with the restriction fused in
         ops.smooth_fused(b, x, y, None, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, 0.5, slots,
                          cb, L1.nx, L1.t0, L1.t1)
-        ops.smooth_fused(b, None, y, None, None, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 3, 0.5, None,
+        # the recompute scheme of the large coarse levels: descent without x output, 9-sweep ascent
+        ops.smooth_fused(b, None, None, None, None, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 3, 0.5, None,
                          cb, L1.nx, L1.t0, L1.t1)
+        ops.smooth_fused(b, None, y, None, c, L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 9, 0.5, None,
+                         prolong_after=3)
         ops.synchronize()
         print(f"rep {k} done", flush=True)
     pts = (L0.t1 - L0.t0) * (L0.nx - 2)

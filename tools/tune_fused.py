@@ -47,10 +47,11 @@ def main():
         ops.stream.synchronize()
         return e0.elapsed_time(e1) / args.iters
 
-    def f(k, pro, zero, res, rs=False):
-        return lambda: ops.smooth_fused(b, None if zero else x, y, r if res else None, c if pro else None, L0.nx, L1.nx,
-                                        L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, k, 0.5, slots if (res or rs) else None,
-                                        cb if rs else None, L1.nx, L1.t0, L1.t1)
+    def f(k, pro, zero, res, rs=False, xout=True, after=0):
+        return lambda: ops.smooth_fused(b, None if zero else x, y if xout else None, r if res else None, c if pro else None,
+                                        L0.nx, L1.nx, L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, k, 0.5,
+                                        slots if (res or rs) else None, cb if rs else None, L1.nx, L1.t0, L1.t1,
+                                        prolong_after=after)
 
     # name: (compulsory bytes/pt of the pass, algorithmic bytes/pt of the separate kernels, fn)
     kernels = {
@@ -65,6 +66,8 @@ def main():
         "P+6J+R+RS": (36, 18 + 144 + 24 + 10, f(6, True, False, True, True)),
         "0+3J+RS": (18, 16 + 48 + 24 + 10, f(3, False, True, False, True)),
         "1J+RS": (26, 24 + 24 + 10, f(1, False, False, False, True)),
+        "0+3J+RS-x": (10, 16 + 48 + 24 + 10, f(3, False, True, False, True, xout=False)),
+        "0+3J+P+6J": (18, 16 + 48 + 18 + 144, f(9, True, True, False, after=3)),
     }
     if args.only:
         kernels = {k: v for k, v in kernels.items() if k in args.only}
