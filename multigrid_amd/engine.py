@@ -58,12 +58,15 @@ class SlabMultigrid:
             rank = dist.get_rank(group) if world > 1 else 0
         self.world, self.rank = world, rank
         self.fused = fused and getattr(ops, "supports_fused", False)
-        if halo is None and world > 1 and not self.fused:
-            halo = 2  # one exchange per sweep needs one row; 2 keeps the halo even
+        if halo is None and world > 1:
+            # fused: as deep as the deepest pass (6 sweeps + residual + restriction = 8; the 9-sweep pass of
+            # the recompute scheme: 10, rounded to 12 so that the halo of every level stays even);
+            # one exchange per sweep needs one row, 2 keeps the halo even
+            halo = (12 if recompute_presmoothing else 8) if self.fused else 2
         # Jacobi levels 0 .. n_dist-1 are distributed, the others replicated on every rank
         n_dist = n_para
         if world > 1:
-            H_ = halo if halo is not None else 8
+            H_ = halo
             R0 = (gny - 1) // world
             n_dist = max(1, sum(1 for l in range(n_para) if (R0 >> l) >= max(dist_min_rows, H_)))
         self.n_dist = n_dist
@@ -255,9 +258,16 @@ class SlabMultigrid:
                 assert restrict and crs is None
                 o.smooth_fused(self.b[l], None, None, r, None, L.nx, cnx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, n, L.h,
                                norm, cb, Lc.nx, Lc.t0, Lc.t1)
+                if to_rep:
+                    self._allgather_b(l + 1)
+                elif dist_:
+                    self._exchange([(self.b[l + 1], Lc, self.plan.halo - 1)])
                 return None
-            # ascent: N1 sweeps from zero, + P(crs), the n post-smoothing sweeps
+            # ascent: N1 sweeps from zero, + P(crs), the n post-smoothing sweeps; of a slab's
+            # neighbours only the correction's halo is needed (b's was exchanged when b was made)
             assert crs is not None and not restrict
+            if dist_ and not crs_has_halo:
+                self._exchange([(crs, self.lv[l + 1], (self.N1 + n) // 2 + 2)])
             o.smooth_fused(self.b[l], None, xa, r, crs, L.nx, cnx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, self.N1 + n, L.h,
                            norm, prolong_after=self.N1)
             return xa
@@ -315,17 +325,33 @@ class SlabMultigrid:
         return src
 
     def _recomputed(self, l):
-        """Does level l run in the recompute scheme?  (Levels that are cut into slabs keep x between the
-        passes: recomputing would need a halo as deep as both smoothings together.)"""
-        if not (self.recompute_presmoothing and self.fused and l >= 1 and (self.world == 1 or l >= self.n_dist)
-                and self.N1 == 3 and self.N2 == 6 and getattr(self.ops, "supports_prolong_after", False)):
+        """Does level l run in the recompute scheme?"""
+        if not (self.recompute_presmoothing and self.fused and l >= 1 and self.N1 == 3 and self.N2 == 6
+                and getattr(self.ops, "supports_prolong_after", False)):
             return False
+        if self.world > 1 and l < self.n_dist and self.plan.halo < self.N1 + self.N2 + 1:
+            return False  # a slab needs a halo as deep as both smoothings together
         # The 9-deep pass pays with wider overlaps (20 of 128 columns, 18 rows per tile end), which a
         # level must be wide enough and have workgroups enough to absorb (measured: it wins from
         # 8193 x 8193 on, loses at 4097 x 4097 and on batches of narrow grids).
         L = self.lv[l]
         blocks = -(-(-(-L.nx // 108)) // 4) * -(-L.rows // 64) * (self.batch or 1)
         return L.nx >= self.recompute_min_nx and blocks >= self.recompute_min_blocks
+
+    def rounds_per_cycle(self):
+        """Communication rounds (neighbour exchanges and the all-gather) one V-cycle issues on this rank,
+        the max-reduction of the norm not counted."""
+        if self.world == 1:
+            return 0
+        k = self.n_dist
+        if not self.fused:
+            return 8 + 11 * (k - 1) + 1
+        total = 2  # finest level: (x, correction) before its pass, b_1 (or the all-gather) after it
+        for l in range(1, k):
+            # after the descent pass: b_{l+1} halo or the all-gather.  Before the ascent pass: x and the
+            # correction -- with the recompute scheme only the correction, and none if that is replicated
+            total += 1 + (0 if (self._recomputed(l) and l + 1 == k) else 1)
+        return total
 
     def _allgather_b(self, lc):
         """Every rank's owned rows of the slab right-hand side of level lc -> the replicated b[lc]."""

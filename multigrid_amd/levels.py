@@ -152,8 +152,10 @@ def exchanges_per_cycle(n_dist, fused=True):
     """Communication rounds one V-cycle performs per rank with n_dist distributed Jacobi levels (see
     engine.SlabMultigrid._cycle), the max-reduction of the norm not counted.  Fused passes: per level
     one halo exchange of (x, correction) before the ascent pass and one of the restricted right-hand
-    side after the descent pass (for the last distributed level that one is the all-gather).  One
-    kernel per operation: an exchange per sweep and one of r per restriction."""
+    side after the descent pass (for the last distributed level that one is the all-gather; a level in
+    the recompute scheme whose correction comes from a replicated level needs no exchange before its
+    ascent pass, see SlabMultigrid.rounds_per_cycle for the exact count).  One kernel per operation:
+    an exchange per sweep and one of r per restriction."""
     return 2 * n_dist if fused else 8 + 11 * (n_dist - 1) + 1
 
 

@@ -147,7 +147,9 @@ class OracleOps:
         if coarse_b is not None:
             # the residual on every row a sweep may touch (halo rows included), Dirichlet cells as r holds them
             rt = r.clone() if r is not None else torch.zeros_like(b)
-            self.residual(rt, cur, b, nx, lo, hi, h, norm if r is None else None)
+            self.residual(rt, cur, b, nx, lo, hi, h)
+            if r is None and norm is not None:  # the norm counts the produced rows only
+                self.residual(torch.zeros_like(b), cur, b, nx, j0, j1, h, norm)
             self.restrict(rt, nx, coarse_b, cbnx, T0, T1, 0, oj)
 
     @_batched
