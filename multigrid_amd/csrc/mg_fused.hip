@@ -559,7 +559,7 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     if (rpb <= 0) {
         // measured at 32769 x 32769 (profiles/): 64-row tiles are as fast as or faster than taller ones at
         // every depth, 32-row tiles faster still for the shallow from-zero pass
-        rpb = D <= 5 ? 32 : 64;
+        rpb = D <= 5 ? 32 : (D >= 9 ? 128 : 64); // the 9-sweep pass streams 9 extra rows per tile end: taller tiles
         while (rpb > 8 * D && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) * a.nbatch < 2048) rpb >>= 1;
     }
     a.rpb = rpb;
