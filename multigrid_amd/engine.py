@@ -46,7 +46,7 @@ class SlabMultigrid:
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
-                 store_residual_every_cycle=False, batch=None, dist_min_rows=256, recompute_presmoothing=True,
+                 store_residual_every_cycle=False, batch=None, dist_min_rows=2048, recompute_presmoothing=True,
                  recompute_min_nx=1024, recompute_min_blocks=1024):
         if ops is None:
             from .ops import HipOps
@@ -63,7 +63,10 @@ class SlabMultigrid:
             # the recompute scheme: 10, rounded to 12 so that the halo of every level stays even);
             # one exchange per sweep needs one row, 2 keeps the halo even
             halo = (12 if recompute_presmoothing else 8) if self.fused else 2
-        # Jacobi levels 0 .. n_dist-1 are distributed, the others replicated on every rank
+        # Jacobi levels 0 .. n_dist-1 are distributed, the others replicated on every rank.  A distributed
+        # level costs two exchange rounds per cycle (~0.1 ms of host time each on RCCL, plus the wire); a
+        # replicated one costs world x its own work.  With 2048 rows per rank (and as many columns) the two
+        # are about equal at 8 ranks; below that replication is cheaper.
         n_dist = n_para
         if world > 1:
             H_ = halo

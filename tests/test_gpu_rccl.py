@@ -1,0 +1,90 @@
+"""The direct (RCCL) branch of SlabComm on a one-rank `nccl` group: RCCL refuses two ranks on one
+device, so the calls the multi-GPU engine makes -- a batch of row sends/receives, the all-gather of
+whole rows into a padded array, the integer MAX-reduction of the norm slots -- are issued here with
+the rank as its own neighbour, on views shaped like the engine's.  Checks that the backend accepts
+the tensors as they are (views, dtypes) and moves the right bytes.  Marked gpu."""
+import os
+import socket
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(port, q):
+    import time
+
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from multigrid_amd.comm import SlabComm
+        from multigrid_amd.ops import HipOps
+        ops = HipOps(torch.device("cuda", 0))
+        comm = SlabComm(ops, None, 1, 0)
+        assert not comm.staged
+        H, rows, ld = 12, 64, 144
+        ops.begin()
+        with ops.ctx():
+            x = torch.arange((rows + 2 * H) * ld, dtype=torch.float64, device="cuda").view(rows + 2 * H, ld)
+            want = x.clone()
+            # the engine's exchange: own rows next to the halo go out, the halo rows come in
+            # (here the lower neighbour's send is this rank's own, so halo_lo <- top own rows and so on)
+            sends = [(x[H:2 * H].view(-1), 0), (x[rows:rows + H].view(-1), 0)]
+            recvs = [(x[rows + H:].view(-1), 0), (x[:H].view(-1), 0)]
+            want[rows + H:] = want[H:2 * H]
+            want[:H] = want[rows:rows + H]
+        batch = comm.prepare(sends, recvs)
+        comm.run(batch)
+        comm.run(batch)  # a prepared batch is issued every cycle
+        with ops.ctx():
+            inp = x[H:H + rows]
+            out = torch.zeros(rows + 5, ld, dtype=torch.float64, device="cuda")
+        comm.allgather_rows(out[2:2 + rows], inp)
+        with ops.ctx():
+            slots = ops.norm_slots()
+            slots[3] = 0x7FF8000000000000  # a NaN's bit pattern stays the maximum
+            slots[5] = 12345
+            before = slots.clone()
+        comm.allreduce_max(slots)
+        ops.stream.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            comm.run(batch)
+        ops.stream.synchronize()
+        per_round = (time.perf_counter() - t0) / 50
+        ops.end()
+        ok = (bool(torch.equal(x, want)), bool(torch.equal(out[2:2 + rows], inp)), bool(out[:2].eq(0).all() and out[2 + rows:].eq(0).all()),
+              bool(torch.equal(slots, before)))
+        q.put((ok, per_round))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slabcomm_direct_branch_on_one_rank_rccl_group():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        ok, per_round = q.get(timeout=150)
+    finally:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    print(f"one exchange round on a one-rank RCCL group: {per_round * 1e6:.0f} us")
+    assert ok == (True, True, True, True)
+    assert p.exitcode == 0
