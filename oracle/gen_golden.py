@@ -435,6 +435,7 @@ SOLVE_CASES = [
     ("m_n6_p3", 6, 3, "main", 0.025, 1, False, "blocks"),
     ("t_n7_p4", 7, 4, "test", 0.025, 2, True, "blocks"),
     ("t_n8_p4", 8, 4, "test", 0.025, 2, True, "sample"),     # the reference's own test size
+    ("m_n8_p4", 8, 4, "main", 0.025, 2, False, "sample"),    # the module's own __main__ (parallel_multigrid.py:351-415)
 ]
 
 

@@ -105,3 +105,23 @@ def test_global_multigrid_aliases_caller_arrays():
     ref.b[:] = b0
     assert mg.solve() == ref.solve() and mg.it == ref.it
     assert np.array_equal(x, ref.x)
+
+
+@pytest.mark.parametrize("name", ["m_n5_p2", "m_n8_p4"])
+def test_module_main_reproduces_the_reference_script(name, tmp_path, capsys):
+    """`python -m multigrid_amd` == the script part of the reference module (parallel_multigrid.py:351-437):
+    same V-cycle counts and errors of both solves as the recorded reference run, and the figure is written."""
+    path = os.path.join(GOLDEN, f"solve_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g = np.load(path)
+    assert str(g["rhs"]) == "main" and int(g["nsolves"]) == 2 and not int(g["mutate"])
+    from multigrid_amd.__main__ import main
+    png = tmp_path / "fig.png"
+    results, a_full, R_full = main(["--n", str(int(g["n"])), "--n-para", str(int(g["n_para"])), "--png", str(png)])
+    assert [it for it, _ in results] == g["its"][0].tolist()
+    assert [err for _, err in results] == g["errs"].max(axis=0).tolist()
+    assert png.stat().st_size > 1000
+    out = capsys.readouterr().out
+    assert out.count("v cycles") == 2 and f"nx = {2 ** int(g['n']) + 1}" in out
+    assert np.isfinite(a_full).all() and np.abs(R_full).max() > 0

@@ -8,7 +8,7 @@ largest grid is covered through properties that do not need the oracle:
     norm equals its max-norm;
   * scaling the right-hand side by a power of two scales the solution by exactly that factor
     (every operation of the cycle is linear and a power-of-two factor commutes with rounding).
-One size down (16385^2, BASELINE's 8-GPU configuration run on one GPU) the engine is compared with
+One size down (16385^2) the engine is compared with
 the oracle itself, bit for bit."""
 import os
 import sys
