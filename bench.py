@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=0,
                     help="B > 0: B independent (2**(n+1)+1)^2 problems advance together on one GPU "
                          "(e.g. --batch 1024 --exp 7 --jacobi-levels 4); not the headline workload")
+    ap.add_argument("--jacobi-omega", type=float, default=1.0,
+                    help="damping of the Jacobi sweeps (1 = the reference's sweep; an option of this build)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages messages through the host: lets several ranks share one GPU (rehearsal only)")
     return ap.parse_args()
@@ -175,7 +177,7 @@ def main():
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
                         use_graph=not args.no_graph, fused=not args.no_fused,
                         eager_dead_levels=not args.lazy_dead_levels, batch=args.batch or None,
-                        recompute_presmoothing=not args.no_recompute)
+                        recompute_presmoothing=not args.no_recompute, jacobi_omega=args.jacobi_omega)
     nprob = args.batch or 1
     fill_rhs(eng, torch, n, rank)
     torch.cuda.synchronize()
@@ -232,7 +234,7 @@ def main():
         pass_ms = timed(lambda k: ops.smooth_fused(eng.b[0], xs[k & 1], xs[1 - (k & 1)], None, crs, L0.nx, L1.nx,
                                                    L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, L0.h, eng.norm,
                                                    eng.b[1], L1.nx, L1.t0, L1.t1))
-        dom_name = ("mg_fused_kernel<6, true, false, true, true, 1, 0> (finest level: prolongation + 6 Jacobi sweeps + "
+        dom_name = ("mg_fused_kernel<6, true, false, true, true, 1, 0, false> (finest level: prolongation + 6 Jacobi sweeps + "
                     "residual + max-norm + restriction)")
         dom_ms = pass_ms
         alg_bpp = 18 + 6 * 24 + 24 + 10  # per-operation compulsory bytes x the operations this launch performs
@@ -262,7 +264,7 @@ def main():
                 "workload": (f"{gny}x{gnx} fp64 Poisson V-cycle ({gnx}x{gnx} per GPU), test.py 8-vortex RHS" if not args.batch
                              else f"{args.batch} independent {gny}x{gnx} fp64 Poisson V-cycles in one batch, test.py 8-vortex RHS"),
                 "n": n, "n_para": n_para, "grid": [gny, gnx], "batch": args.batch or None, "unknowns": unknowns,
-                "coarse_ordering": args.ordering, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
+                "coarse_ordering": args.ordering, "jacobi_omega": args.jacobi_omega, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
                 "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph), "fused_passes": bool(eng.fused), "recompute_presmoothing": bool(eng.recompute_presmoothing and eng.fused),
                 "halo_rows": eng.plan.halo, "distributed_levels": eng.n_dist if world > 1 else None,
                 "dead_whole_domain_levels": "computed every cycle" if eng.eager_dead_levels else "on demand", "backend": args.backend if world > 1 else None,

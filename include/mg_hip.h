@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 3
+#define MG_ABI_VERSION 4
 
 /* flags for the stencil entry points */
 #define MG_FLAG_FINEST 1 /* launch the instantiation named "...finest..." (profiler attribution only) */
@@ -55,17 +55,24 @@ int mg_set_tuning(const char *key, int value);
  * copies the whole scratch array back (second loop); here the caller swaps x and x_out instead,
  * which is equivalent when the boundary/halo cells of both arrays hold the same values.
  * x_out must not alias x.
+ * omega = 1 is the reference's sweep.  0 < omega < 1 damps it: with t the value above,
+ *     x_out[j,i] = x[j,i] + omega * (t - x[j,i])
+ * (no counterpart in the reference, whose undamped sweep leaves the checkerboard mode of the error
+ * untouched, so that its residual stalls at that mode's share of the right-hand side).
  */
 int mg_jacobi(const double *b, const double *x, double *x_out, int64_t ny, int64_t nx, int64_t ld,
-              int64_t j0, int64_t j1, double h, int64_t nbatch, int64_t bstride, int flags, void *stream);
+              int64_t j0, int64_t j1, double h, double omega, int64_t nbatch, int64_t bstride, int flags,
+              void *stream);
 
 /*
  * The first Jacobi sweep from x = 0 without reading x:  x_out[j,i] = 0.25 * (0.0 - h*h * b[j,i]),
  * the value the sweep above produces when x is all zeros (parallel_multigrid.py:276 zeroes x
- * before smooth_parallel).  Interior cells of rows j0..j1-1 only.
+ * before smooth_parallel).  Interior cells of rows j0..j1-1 only.  omega as in mg_jacobi
+ * (x_out = 0.0 + omega * (t - 0.0)).
  */
 int mg_jacobi_from_zero(const double *b, double *x_out, int64_t ny, int64_t nx, int64_t ld, int64_t j0,
-                        int64_t j1, double h, int64_t nbatch, int64_t bstride, int flags, void *stream);
+                        int64_t j1, double h, double omega, int64_t nbatch, int64_t bstride, int flags,
+                        void *stream);
 
 /*
  * Residual r = b - laplacian(x), rows j0 <= j < j1, interior columns, evaluated as
@@ -138,12 +145,14 @@ int mg_prolong_add(const double *crs, int64_t cny, int64_t cnx, int64_t cld, dou
  * with sweeps = 9, x_in = NULL: a coarse level's whole smoothing in one pass -- 3 sweeps from x = 0
  * (parallel_multigrid.py:276-277), += P(crs) (:309), 6 more sweeps (:310) -- so that the descent need not
  * store x (mg_smooth_fused_restrict with x_out = NULL) and the ascent need not read it.
+ * omega: every sweep of the pass is damped as in mg_jacobi; omega != 1 is built for 1, 3 and 6 sweeps
+ * per pass (and 9 with prolong_after = 3), the depths of the V-cycle.
  */
 int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
                     int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld, int64_t j0,
                     int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps, int prolong_after,
-                    double h, uint64_t *norm_slots, int64_t nbatch, int64_t bstride, int64_t cstride,
-                    void *stream);
+                    double h, double omega, uint64_t *norm_slots, int64_t nbatch, int64_t bstride,
+                    int64_t cstride, void *stream);
 /*
  * mg_smooth_fused with the full-weighting restriction of the residual fused in as a last stage:
  * coarse rows T0 <= T < T1 of coarse_b (cbny x cbnx, interior columns) are written as mg_restrict
@@ -157,7 +166,7 @@ int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *
 int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
                              int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld,
                              int64_t j0, int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps,
-                             double h, uint64_t *norm_slots, double *coarse_b, int64_t cbny, int64_t cbnx,
+                             double h, double omega, uint64_t *norm_slots, double *coarse_b, int64_t cbny, int64_t cbnx,
                              int64_t cbld, int64_t T0, int64_t T1, int64_t nbatch, int64_t bstride,
                              int64_t cstride, int64_t cbstride, void *stream);
 /* Tuning knobs of mg_smooth_fused: column pairs per lane (1 or 2), rows per tile (0 = automatic). */

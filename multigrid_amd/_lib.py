@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 NORM_SLOTS = 64
 FLAG_FINEST = 1
 SOR_LEXICOGRAPHIC = 0
@@ -31,8 +31,8 @@ SIGNATURES = {
     "mg_abi_version": ([], _n),
     "mg_last_error": ([], C.c_char_p),
     "mg_set_tuning": ([C.c_char_p, _n], _n),
-    "mg_jacobi": ([_p, _p, _p, _i, _i, _i, _i, _i, _d, _i, _i, _n, _p], _n),
-    "mg_jacobi_from_zero": ([_p, _p, _i, _i, _i, _i, _i, _d, _i, _i, _n, _p], _n),
+    "mg_jacobi": ([_p, _p, _p, _i, _i, _i, _i, _i, _d, _d, _i, _i, _n, _p], _n),
+    "mg_jacobi_from_zero": ([_p, _p, _i, _i, _i, _i, _i, _d, _d, _i, _i, _n, _p], _n),
     "mg_residual": ([_p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _i, _i, _n, _p], _n),
     "mg_laplacian": ([_p, _p, _i, _i, _i, _d, _p], _n),
     "mg_norm_reset": ([_p, _p], _n),
@@ -40,8 +40,8 @@ SIGNATURES = {
     "mg_maxabs": ([_p, _i, _i, _i, _p, _p], _n),
     "mg_restrict": ([_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _n),
     "mg_prolong_add": ([_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _n),
-    "mg_smooth_fused": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _n, _d, _p, _i, _i, _i, _p], _n),
-    "mg_smooth_fused_restrict": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _d, _p, _p, _i, _i,
+    "mg_smooth_fused": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _n, _d, _d, _p, _i, _i, _i, _p], _n),
+    "mg_smooth_fused_restrict": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _d, _d, _p, _p, _i, _i,
                                   _i, _i, _i, _i, _i, _i, _i, _p], _n),
     "mg_set_fused_tuning": ([_n, _n], _n),
     "mg_sor": ([_p, _p, _p, _i, _i, _i, _d, _i, _n, _n, _i, _i, _p], _n),

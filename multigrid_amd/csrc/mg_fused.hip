@@ -38,6 +38,7 @@ struct FusedArgs {
     i64 flo, fhi;        // rows <= flo and >= fhi are fixed (Dirichlet): passed through
     int rpb, ncb, nrc, ntc, oj;
     double h2, hh;
+    double om; // damped Jacobi: x + om * (t - x), t the undamped value (DAMPED instantiations only)
     u64 *norm;
     double *cb;          // coarse right-hand side produced by the fused restriction (RESTRICT)
     i64 cbnx, cbld, T0, T1; // its columns, leading dimension, and the coarse rows to produce
@@ -84,7 +85,7 @@ using int_c = std::integral_constant<int, N>;
 // sweep (x += P(c), then K sweeps).  PS > 0 goes with ZERO: PS sweeps from x = 0, += P(c), K - PS
 // more sweeps -- a coarse level's pre-smoothing recomputed in front of its post-smoothing, so that
 // the descent need not store x and the ascent need not read it.
-template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0>
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0, bool DAMPED = false>
 __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
 {
     FusedArgs a = a0; // blockIdx.y = grid of the batch
@@ -220,6 +221,8 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
         double C0[3][U], C1[3][U], Ce[3] = {0, 0, 0};
         const int oj = a.oj;
         const double h2 = a.h2, hh = a.hh;
+        const double om = a.om;
+        (void)om;
 
         // PL: no Dirichlet cell, no clamped row or column in anything this wave streams.
         auto run = [&](auto plain_c) {
@@ -363,8 +366,9 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                             east = isR ? t : east;
                         }
                         const double c0v = w[s - 1][Q1][g][0], c1v = w[s - 1][Q1][g][1];
-                        const double j0v = 0.25 * (c1v + west + w[s - 1][Q2][g][0] + w[s - 1][Q0][g][0] - h2 * bs[g][0]);
-                        const double j1v = 0.25 * (east + c0v + w[s - 1][Q2][g][1] + w[s - 1][Q0][g][1] - h2 * bs[g][1]);
+                        double j0v = 0.25 * (c1v + west + w[s - 1][Q2][g][0] + w[s - 1][Q0][g][0] - h2 * bs[g][0]);
+                        double j1v = 0.25 * (east + c0v + w[s - 1][Q2][g][1] + w[s - 1][Q0][g][1] - h2 * bs[g][1]);
+                        if constexpr (DAMPED) j0v = c0v + om * (j0v - c0v), j1v = c1v + om * (j1v - c1v);
                         o[g][0] = (PL || (rint && ic[g][0])) ? j0v : c0v;
                         o[g][1] = (PL || (rint && ic[g][1])) ? j1v : c1v;
                     }
@@ -547,7 +551,7 @@ extern "C" int mg_set_fused_tuning(int unroll, int rows)
     return 0;
 }
 
-template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0>
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0, bool DAMPED = false>
 static int launch_fused(FusedArgs a, hipStream_t st)
 {
     constexpr int D = K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0), Dv = (D + 1) & ~1, W = 128 * U, STRIDE = W - 2 * Dv;
@@ -564,14 +568,14 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     }
     a.rpb = rpb;
     a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
-    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U, PS>),
+    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U, PS, DAMPED>),
                        dim3((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), dim3(64 * wpb),
                        DK >= 5 ? (size_t)wpb * ((DK + 1) / 3 + 1) * 3 * W * sizeof(double) : 0, st, a);
     MG_LAUNCH_CHECK("mg_smooth_fused");
     return 0;
 }
 
-template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT>
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, bool DAMPED>
 static int pick_u(const FusedArgs &a, hipStream_t st)
 {
     // deep pipelines keep D three-row windows per column pair in registers: one pair per lane then
@@ -580,28 +584,28 @@ static int pick_u(const FusedArgs &a, hipStream_t st)
     if constexpr (!PROLONG && (K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0) + (ZERO ? 0 : 1)) <= 3) {
         int u = g_fused_unroll;
         while (u > 1 && a.nx < 128 * u) u >>= 1;
-        if (u == 2) return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 2>(a, st);
+        if (u == 2) return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 2, 0, DAMPED>(a, st);
     }
-    return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 1>(a, st);
+    return launch_fused<K, PROLONG, ZERO, RESID, RESTRICT, 1, 0, DAMPED>(a, st);
 }
 
-template <int K>
+template <int K, bool DAMPED = false>
 static int pick_mode(const FusedArgs &a, bool prolong, bool zero, bool resid, bool restr, hipStream_t st)
 {
     if (restr) {
-        if (zero) return pick_u<K, false, true, true, true>(a, st);
-        if (prolong) return pick_u<K, true, false, true, true>(a, st);
-        return pick_u<K, false, false, true, true>(a, st);
+        if (zero) return pick_u<K, false, true, true, true, DAMPED>(a, st);
+        if (prolong) return pick_u<K, true, false, true, true, DAMPED>(a, st);
+        return pick_u<K, false, false, true, true, DAMPED>(a, st);
     }
-    if (zero) return resid ? pick_u<K, false, true, true, false>(a, st) : pick_u<K, false, true, false, false>(a, st);
-    if (prolong) return resid ? pick_u<K, true, false, true, false>(a, st) : pick_u<K, true, false, false, false>(a, st);
-    return resid ? pick_u<K, false, false, true, false>(a, st) : pick_u<K, false, false, false, false>(a, st);
+    if (zero) return resid ? pick_u<K, false, true, true, false, DAMPED>(a, st) : pick_u<K, false, true, false, false, DAMPED>(a, st);
+    if (prolong) return resid ? pick_u<K, true, false, true, false, DAMPED>(a, st) : pick_u<K, true, false, false, false, DAMPED>(a, st);
+    return resid ? pick_u<K, false, false, true, false, DAMPED>(a, st) : pick_u<K, false, false, false, false, DAMPED>(a, st);
 }
 
 static int smooth_fused_impl(const double *b, const double *x_in, double *x_out, double *r, const double *crs, i64 ny,
                              i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo, i64 fix_hi,
-                             i64 ofst_j, int sweeps, int prolong_after, double h, uint64_t *norm_slots, bool want_resid,
-                             double *coarse_b,
+                             i64 ofst_j, int sweeps, int prolong_after, double h, double omega, uint64_t *norm_slots,
+                             bool want_resid, double *coarse_b,
                              i64 cbny, i64 cbnx, i64 cbld, i64 T0, i64 T1, i64 nbatch, i64 bstride, i64 cstride,
                              i64 cbstride, void *stream)
 {
@@ -617,6 +621,7 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
     } else {
         MG_REQUIRE(sweeps >= 1 && sweeps <= 6, "mg_smooth_fused: 1..6 sweeps per pass, got %d", sweeps);
     }
+    MG_REQUIRE(omega > 0 && omega <= 1, "mg_smooth_fused: omega %g outside (0, 1]", omega);
     MG_REQUIRE(ny >= 3 && nx >= 3 && ld >= nx, "mg_smooth_fused: bad shape");
     MG_REQUIRE(ld % 2 == 0 && mg_aligned(b, 16) && (!x_out || mg_aligned(x_out, 16)) && (!x_in || mg_aligned(x_in, 16)) &&
                    (!r || mg_aligned(r, 16)),
@@ -656,13 +661,25 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
     a.b = b, a.xin = x_in, a.xout = x_out, a.r = r, a.crs = crs;
     a.ny = ny, a.nx = nx, a.ld = ld, a.cny = cny, a.cnx = cnx, a.cld = cld;
     a.j0 = j0, a.j1 = j1, a.flo = fix_lo, a.fhi = fix_hi, a.oj = (int)ofst_j;
-    a.h2 = h * h, a.hh = 1 / (h * h), a.norm = (u64 *)norm_slots;
+    a.h2 = h * h, a.hh = 1 / (h * h), a.om = omega, a.norm = (u64 *)norm_slots;
     a.rpb = a.ncb = a.nrc = a.ntc = 0;
     a.cb = coarse_b, a.cbnx = cbnx, a.cbld = cbld, a.T0 = T0, a.T1 = T1;
     a.nbatch = nbatch, a.bstride = bstride, a.cstride = cstride, a.cbstride = cbstride;
     const bool zero = x_in == nullptr, prolong = crs != nullptr, restr = coarse_b != nullptr;
     const bool resid = want_resid || restr;
     hipStream_t st = (hipStream_t)stream;
+    if (omega != 1.0) {
+        // damped sweeps: the pass depths the V-cycle uses
+        if (prolong_after > 0)
+            return resid ? launch_fused<9, true, true, true, false, 1, 3, true>(a, st)
+                         : launch_fused<9, true, true, false, false, 1, 3, true>(a, st);
+        switch (sweeps) {
+        case 1: return pick_mode<1, true>(a, prolong, zero, resid, restr, st);
+        case 3: return pick_mode<3, true>(a, prolong, zero, resid, restr, st);
+        case 6: return pick_mode<6, true>(a, prolong, zero, resid, restr, st);
+        default: mg_set_error("mg_smooth_fused: damped sweeps (omega != 1) are built for 1, 3 or 6 sweeps per pass, got %d", sweeps); return 1;
+        }
+    }
     if (prolong_after > 0)
         return resid ? launch_fused<9, true, true, true, false, 1, 3>(a, st) : launch_fused<9, true, true, false, false, 1, 3>(a, st);
     switch (sweeps) {
@@ -677,22 +694,22 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
 
 extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
                                i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo,
-                               i64 fix_hi, i64 ofst_j, int sweeps, int prolong_after, double h,
+                               i64 fix_hi, i64 ofst_j, int sweeps, int prolong_after, double h, double omega,
                                uint64_t *norm_slots, i64 nbatch, i64 bstride, i64 cstride, void *stream)
 {
     return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
-                             prolong_after, h, norm_slots, r != nullptr, nullptr, 0, 0, 0, 0, 0, nbatch, bstride, cstride,
-                             0, stream);
+                             prolong_after, h, omega, norm_slots, r != nullptr, nullptr, 0, 0, 0, 0, 0, nbatch, bstride,
+                             cstride, 0, stream);
 }
 
 extern "C" int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out, double *r,
                                         const double *crs, i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0,
-                                        i64 j1, i64 fix_lo, i64 fix_hi, i64 ofst_j, int sweeps, double h,
+                                        i64 j1, i64 fix_lo, i64 fix_hi, i64 ofst_j, int sweeps, double h, double omega,
                                         uint64_t *norm_slots, double *coarse_b, i64 cbny, i64 cbnx, i64 cbld, i64 T0,
                                         i64 T1, i64 nbatch, i64 bstride, i64 cstride, i64 cbstride, void *stream)
 {
     MG_REQUIRE(coarse_b, "mg_smooth_fused_restrict: null coarse array");
     return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
-                             0, h, norm_slots, true, coarse_b, cbny, cbnx, cbld, T0, T1, nbatch, bstride, cstride,
+                             0, h, omega, norm_slots, true, coarse_b, cbny, cbnx, cbld, T0, T1, nbatch, bstride, cstride,
                              cbstride, stream);
 }

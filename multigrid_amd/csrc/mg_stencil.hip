@@ -26,7 +26,7 @@ template <int OP, int V, int U, bool FINEST>
 __global__ __launch_bounds__(256) void mg_stencil5_kernel(const double *__restrict__ b, const double *__restrict__ x,
                                                           double *__restrict__ out, i64 nx, i64 ld, i64 j0, i64 j1,
                                                           int rpb, int ncb, int nrc, int linear_map, double s,
-                                                          i64 bstride, u64 *__restrict__ norm_slots)
+                                                          double om, i64 bstride, u64 *__restrict__ norm_slots)
 {
     constexpr int WT = 64 * V * U; // wave tile width in columns
     constexpr int GS = 64 * V;     // column stride between the groups of a lane
@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void mg_stencil5_kernel(const double *__restri
     const i64 rb = j0 + (i64)rc * rpb;
     const i64 re = rb + rpb < j1 ? rb + rpb : j1;
     u64 nmax = 0;
+    // damped Jacobi: x + om * (t - x) with t the undamped value; om == 1 keeps t itself (uniform)
+    const bool damped = om != 1.0;
+    (void)damped;
 
     // Writes a row of results.  Groups that straddle the interior (column 0, columns >= nx-1) blend
     // the cells outside it with what `out` already holds, so every store is a whole aligned vector.
@@ -91,7 +94,10 @@ __global__ __launch_bounds__(256) void mg_stencil5_kernel(const double *__restri
                     double bb[V];
                     ldv<V>(bb, b + j * ld + cl[k]);
 #pragma unroll
-                    for (int v = 0; v < V; ++v) o[k][v] = 0.25 * (0.0 - s * bb[v]);
+                    for (int v = 0; v < V; ++v) {
+                        const double t = 0.25 * (0.0 - s * bb[v]);
+                        o[k][v] = damped ? 0.0 + om * (t - 0.0) : t;
+                    }
                 }
                 store_row(out + j * ld, o);
             }
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(256) void mg_stencil5_kernel(const double *__restri
                         const double E = v + 1 < V ? cur[k][v + 1 < V ? v + 1 : 0] : east;
                         const double W = v > 0 ? cur[k][v > 0 ? v - 1 : 0] : west;
                         if constexpr (OP == OP_JACOBI) {
-                            o[k][v] = 0.25 * (E + W + dn[k][v] + up[k][v] - s * bb[k][v]);
+                            const double t = 0.25 * (E + W + dn[k][v] + up[k][v] - s * bb[k][v]);
+                            o[k][v] = damped ? cur[k][v] + om * (t - cur[k][v]) : t;
                         } else if constexpr (OP == OP_LAPLACE) {
                             o[k][v] = (W + E + up[k][v] + dn[k][v] - 4 * cur[k][v]) * s;
                         } else {
@@ -259,7 +266,7 @@ static int rows_per_block(i64 nrows, int ncb, i64 nbatch)
 
 template <int OP, int V, int U>
 static int launch_stencil(const double *b, const double *x, double *out, i64 nx, i64 ld, i64 j0, i64 j1, double s,
-                          i64 nbatch, i64 bstride, u64 *slots, int flags, hipStream_t st, const char *name)
+                          double om, i64 nbatch, i64 bstride, u64 *slots, int flags, hipStream_t st, const char *name)
 {
     const int bw = 256 * V * U;                        // columns per workgroup
     const int ncb = (int)((nx - 1 + bw - 1) / bw);     // columns 0 .. nx-2 need a lane
@@ -268,10 +275,10 @@ static int launch_stencil(const double *b, const double *x, double *out, i64 nx,
     dim3 grid((unsigned)(ncb * nrc), (unsigned)nbatch);
     if (flags & MG_FLAG_FINEST)
         hipLaunchKernelGGL((mg_stencil5_kernel<OP, V, U, true>), grid, dim3(256), 0, st, b, x, out, nx, ld, j0, j1,
-                           rpb, ncb, nrc, g_linear_map, s, bstride, slots);
+                           rpb, ncb, nrc, g_linear_map, s, om, bstride, slots);
     else
         hipLaunchKernelGGL((mg_stencil5_kernel<OP, V, U, false>), grid, dim3(256), 0, st, b, x, out, nx, ld, j0, j1,
-                           rpb, ncb, nrc, g_linear_map, s, bstride, slots);
+                           rpb, ncb, nrc, g_linear_map, s, om, bstride, slots);
     MG_LAUNCH_CHECK(name);
     return 0;
 }
@@ -317,25 +324,27 @@ static int pick_unroll(i64 nx, int v)
     } while (0)
 
 extern "C" int mg_jacobi(const double *b, const double *x, double *x_out, i64 ny, i64 nx, i64 ld, i64 j0, i64 j1,
-                         double h, i64 nbatch, i64 bstride, int flags, void *stream)
+                         double h, double omega, i64 nbatch, i64 bstride, int flags, void *stream)
 {
+    MG_REQUIRE(omega > 0 && omega <= 1, "mg_jacobi: omega %g outside (0, 1]", omega);
     if (check_grid("mg_jacobi", ny, nx, ld, j0, j1, nbatch, bstride)) return 1;
     MG_REQUIRE(b && x && x_out, "mg_jacobi: null array");
     MG_REQUIRE(x != x_out, "mg_jacobi: x_out aliases x");
     if (j0 == j1) return 0;
     const int v = vec_width(ld, bstride, nbatch, b, x, x_out);
-    DISPATCH_VU(OP_JACOBI, b, x, x_out, nx, ld, j0, j1, h * h, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
+    DISPATCH_VU(OP_JACOBI, b, x, x_out, nx, ld, j0, j1, h * h, omega, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
                 "mg_jacobi");
 }
 
 extern "C" int mg_jacobi_from_zero(const double *b, double *x_out, i64 ny, i64 nx, i64 ld, i64 j0, i64 j1, double h,
-                                   i64 nbatch, i64 bstride, int flags, void *stream)
+                                   double omega, i64 nbatch, i64 bstride, int flags, void *stream)
 {
+    MG_REQUIRE(omega > 0 && omega <= 1, "mg_jacobi_from_zero: omega %g outside (0, 1]", omega);
     if (check_grid("mg_jacobi_from_zero", ny, nx, ld, j0, j1, nbatch, bstride)) return 1;
     MG_REQUIRE(b && x_out, "mg_jacobi_from_zero: null array");
     if (j0 == j1) return 0;
     const int v = vec_width(ld, bstride, nbatch, b, x_out, nullptr);
-    DISPATCH_VU(OP_JACOBI_ZERO, b, nullptr, x_out, nx, ld, j0, j1, h * h, nbatch, bstride, nullptr, flags,
+    DISPATCH_VU(OP_JACOBI_ZERO, b, nullptr, x_out, nx, ld, j0, j1, h * h, omega, nbatch, bstride, nullptr, flags,
                 (hipStream_t)stream, "mg_jacobi_from_zero");
 }
 
@@ -349,9 +358,9 @@ extern "C" int mg_residual(double *r, const double *x, const double *b, i64 ny, 
     const int v = vec_width(ld, bstride, nbatch, b, x, r);
     const double hh = 1 / (h * h);
     if (norm_slots)
-        DISPATCH_VU(OP_RESID_NORM, b, x, r, nx, ld, j0, j1, hh, nbatch, bstride, (u64 *)norm_slots, flags,
+        DISPATCH_VU(OP_RESID_NORM, b, x, r, nx, ld, j0, j1, hh, 1.0, nbatch, bstride, (u64 *)norm_slots, flags,
                     (hipStream_t)stream, "mg_residual");
-    DISPATCH_VU(OP_RESID, b, x, r, nx, ld, j0, j1, hh, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
+    DISPATCH_VU(OP_RESID, b, x, r, nx, ld, j0, j1, hh, 1.0, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
                 "mg_residual");
 }
 
@@ -360,7 +369,7 @@ extern "C" int mg_laplacian(const double *x, double *lplc, i64 ny, i64 nx, i64 l
     if (check_grid("mg_laplacian", ny, nx, ld, 1, ny - 1, 1, 0)) return 1;
     MG_REQUIRE(x && lplc && x != lplc, "mg_laplacian: null or aliased array");
     const int v = vec_width(ld, 0, 1, x, lplc, nullptr);
-    DISPATCH_VU(OP_LAPLACE, nullptr, x, lplc, nx, ld, 1, ny - 1, 1 / (h * h), 1, 0, nullptr, 0, (hipStream_t)stream,
+    DISPATCH_VU(OP_LAPLACE, nullptr, x, lplc, nx, ld, 1, ny - 1, 1 / (h * h), 1.0, 1, 0, nullptr, 0, (hipStream_t)stream,
                 "mg_laplacian");
 }
 

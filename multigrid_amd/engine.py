@@ -47,7 +47,7 @@ class SlabMultigrid:
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
                  store_residual_every_cycle=False, batch=None, dist_min_rows=2048, recompute_presmoothing=True,
-                 recompute_min_nx=1024, recompute_min_blocks=1024):
+                 recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -90,6 +90,13 @@ class SlabMultigrid:
         self.fix_coarse_ascent = fix_coarse_ascent
         self.keep_ascent_residuals = keep_ascent_residuals
         self.max_cycles = max_cycles
+        # 1 = the reference's Jacobi sweep.  It leaves the checkerboard mode of the error undamped (eigenvalue
+        # -1) and the restriction does not see that mode, so max|r| stalls at the mode's share of the
+        # right-hand side; 0 < jacobi_omega < 1 (0.8 is the usual choice) damps every sweep,
+        # x + omega * (t - x), and lets the cycle converge to rounding level.
+        if not 0 < jacobi_omega <= 1:
+            raise ValueError("jacobi_omega must be in (0, 1]")
+        self.jacobi_omega = float(jacobi_omega)
         # On a level that is not cut into slabs the post-smoothing pass recomputes the pre-smoothing sweeps
         # (from x = 0, 3 sweeps) in front of its own instead of reading their result: the descent pass then
         # need not store x at all.  16 B per point less traffic on every coarse level, identical values.
@@ -260,7 +267,7 @@ class SlabMultigrid:
             if src is None:  # descent: only the restricted residual leaves the pass
                 assert restrict and crs is None
                 o.smooth_fused(self.b[l], None, None, r, None, L.nx, cnx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, n, L.h,
-                               norm, cb, Lc.nx, Lc.t0, Lc.t1)
+                               norm, cb, Lc.nx, Lc.t0, Lc.t1, omega=self.jacobi_omega)
                 if to_rep:
                     self._allgather_b(l + 1)
                 elif dist_:
@@ -272,7 +279,7 @@ class SlabMultigrid:
             if dist_ and not crs_has_halo:
                 self._exchange([(crs, self.lv[l + 1], (self.N1 + n) // 2 + 2)])
             o.smooth_fused(self.b[l], None, xa, r, crs, L.nx, cnx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, self.N1 + n, L.h,
-                           norm, prolong_after=self.N1)
+                           norm, prolong_after=self.N1, omega=self.jacobi_omega)
             return xa
         if self.fused:
             extra = (2 if restrict else 1 if r is not None else 0)
@@ -290,10 +297,10 @@ class SlabMultigrid:
                     o.norm_reset(norm)
                 if last and restrict:
                     o.smooth_fused(self.b[l], src, dst, r, crs if first else None, L.nx, cnx, L.t0, L.t1, L.fix_lo,
-                                   L.fix_hi, L.oj, k, L.h, norm, cb, Lc.nx, Lc.t0, Lc.t1)
+                                   L.fix_hi, L.oj, k, L.h, norm, cb, Lc.nx, Lc.t0, Lc.t1, omega=self.jacobi_omega)
                 else:
                     o.smooth_fused(self.b[l], src, dst, r if last else None, crs if first else None, L.nx, cnx, L.t0,
-                                   L.t1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None)
+                                   L.t1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None, omega=self.jacobi_omega)
                 src = dst
             if restrict and to_rep:
                 self._allgather_b(l + 1)
@@ -302,7 +309,7 @@ class SlabMultigrid:
             return src
         # one kernel per operation, one single-row exchange per sweep
         if src is None:
-            o.jacobi_from_zero(self.b[l], xa, L.nx, L.t0, L.t1, L.h, finest)
+            o.jacobi_from_zero(self.b[l], xa, L.nx, L.t0, L.t1, L.h, finest, omega=self.jacobi_omega)
             src, n = xa, n - 1
         else:
             if crs is not None:  # its lower halo row is valid: last exchanged after its last sweep
@@ -311,7 +318,7 @@ class SlabMultigrid:
             self._exchange([(src, L, 1)])
         for _ in range(n):
             dst = xb if src is xa else xa
-            o.jacobi(self.b[l], src, dst, L.nx, L.t0, L.t1, L.h, finest)
+            o.jacobi(self.b[l], src, dst, L.nx, L.t0, L.t1, L.h, finest, omega=self.jacobi_omega)
             if dist_:
                 self._exchange([(dst, L, 1)])
             src = dst

@@ -137,7 +137,7 @@ def smooth_sweep_jacobi(b, a, a_temp, h):
     ny, nx, ld = _same_shape("smooth_sweep_jacobi", tb, ta, tt)
     with torch.cuda.device(g.device):
         L = lib()
-        check(L.mg_jacobi(tb.data_ptr(), ta.data_ptr(), tt.data_ptr(), ny, nx, ld, 1, ny - 1, float(h), 1, 0, 0,
+        check(L.mg_jacobi(tb.data_ptr(), ta.data_ptr(), tt.data_ptr(), ny, nx, ld, 1, ny - 1, float(h), 1.0, 1, 0, 0,
                           _stream()))
         check(L.mg_copy2d(ta.data_ptr(), ld, tt.data_ptr(), ld, ny, nx, _stream()))
     g.finish()

@@ -103,16 +103,16 @@ class HipOps:
             raise _lib.MgError("arrays of one launch must share shape and strides: " +
                                ", ".join(f"{tuple(t.shape)}/{t.stride()}" for t in ts))
 
-    def jacobi(self, b, x, xo, nx, j0, j1, h, finest=False):
+    def jacobi(self, b, x, xo, nx, j0, j1, h, finest=False, omega=1.0):
         self._same_layout(b, x, xo)
         nb, bs, ny, ld = self._nb(x)
-        check(self.L.mg_jacobi(b.data_ptr(), x.data_ptr(), xo.data_ptr(), ny, nx, ld, j0, j1, h, nb, bs,
+        check(self.L.mg_jacobi(b.data_ptr(), x.data_ptr(), xo.data_ptr(), ny, nx, ld, j0, j1, h, omega, nb, bs,
                                _lib.FLAG_FINEST if finest else 0, self._s))
 
-    def jacobi_from_zero(self, b, xo, nx, j0, j1, h, finest=False):
+    def jacobi_from_zero(self, b, xo, nx, j0, j1, h, finest=False, omega=1.0):
         self._same_layout(b, xo)
         nb, bs, ny, ld = self._nb(xo)
-        check(self.L.mg_jacobi_from_zero(b.data_ptr(), xo.data_ptr(), ny, nx, ld, j0, j1, h, nb, bs,
+        check(self.L.mg_jacobi_from_zero(b.data_ptr(), xo.data_ptr(), ny, nx, ld, j0, j1, h, omega, nb, bs,
                                          _lib.FLAG_FINEST if finest else 0, self._s))
 
     def residual(self, r, x, b, nx, j0, j1, h, norm=None, finest=False):
@@ -138,21 +138,22 @@ class HipOps:
     supports_prolong_after = True
 
     def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
-                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0):
+                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0, omega=1.0):
         """[x_in += P(crs)] -> `sweeps` Jacobi sweeps -> [residual] -> [restriction into coarse_b];
         x_in None = start from zero; x_out None (with coarse_b) = x is not stored; prolong_after = n:
-        the prolongation is added after the first n sweeps (from zero) instead of before the first."""
+        the prolongation is added after the first n sweeps (from zero) instead of before the first;
+        omega < 1: damped sweeps, x + omega * (t - x)."""
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         self._same_layout(b, x_in, x_out, r)
         nb, bs, ny, ld = self._nb(b)
         _, cs, cny, cld = self._nb(crs) if crs is not None else (1, 0, 0, 0)
         common = (p(b), p(x_in), p(x_out), p(r), p(crs), ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, oj, sweeps)
         if coarse_b is None:
-            check(self.L.mg_smooth_fused(*common, prolong_after, h, p(norm), nb, bs, cs, self._s))
+            check(self.L.mg_smooth_fused(*common, prolong_after, h, omega, p(norm), nb, bs, cs, self._s))
         else:
             _, cbs, cbny, cbld = self._nb(coarse_b)
             assert prolong_after == 0
-            check(self.L.mg_smooth_fused_restrict(*common, h, p(norm), p(coarse_b), cbny, cbnx, cbld, T0, T1, nb, bs, cs, cbs,
+            check(self.L.mg_smooth_fused_restrict(*common, h, omega, p(norm), p(coarse_b), cbny, cbnx, cbld, T0, T1, nb, bs, cs, cbs,
                                                   self._s))
 
     def sor(self, b, x, r, nx, h, iterations, ordering):

@@ -109,7 +109,7 @@ class BlockWorld:
         check(L.mg_copy2d(tmp.data_ptr(), ld, x.data_ptr(), ld, 4 * m, m, s))
         self._exchange(x, m, ld)
         for _ in range(iterations):
-            check(L.mg_jacobi(b.data_ptr(), x.data_ptr(), tmp.data_ptr(), m, m, ld, 1, m - 1, h, 4, m * ld, 0, s))
+            check(L.mg_jacobi(b.data_ptr(), x.data_ptr(), tmp.data_ptr(), m, m, ld, 1, m - 1, h, 1.0, 4, m * ld, 0, s))
             check(L.mg_copy2d(x.data_ptr(), ld, tmp.data_ptr(), ld, 4 * m, m, s))
             self._exchange(x, m, ld)
         check(L.mg_residual(r.data_ptr(), x.data_ptr(), b.data_ptr(), m, m, ld, 1, m - 1, h, None, 4, m * ld, 0, s))

@@ -112,6 +112,27 @@ void orc_smooth_sweep_jacobi(const double *b, double *a, double *a_temp, i64 ny,
             a[j * nx + i] = a_temp[j * nx + i];
 }
 
+/*
+ * The sweep above with damping: a_temp = a + omega * (t - a), t the undamped value.  No counterpart in
+ * the reference (its omega is 1, which leaves the checkerboard error mode undamped); omega = 1 is NOT
+ * routed here, so the reference's arithmetic stays untouched.
+ */
+void orc_smooth_sweep_jacobi_damped(const double *b, double *a, double *a_temp, i64 ny, i64 nx, double h, double omega)
+{
+    double h2 = h * h;
+#pragma omp parallel for schedule(static)
+    for (i64 j = 1; j < ny - 1; j++)
+        for (i64 i = 1; i < nx - 1; i++) {
+            double t = 0.25 * (a[j * nx + i + 1] + a[j * nx + i - 1] + a[(j + 1) * nx + i] + a[(j - 1) * nx + i] -
+                               h2 * b[j * nx + i]);
+            a_temp[j * nx + i] = a[j * nx + i] + omega * (t - a[j * nx + i]);
+        }
+#pragma omp parallel for schedule(static)
+    for (i64 j = 0; j < ny; j++)
+        for (i64 i = 0; i < nx; i++)
+            a[j * nx + i] = a_temp[j * nx + i];
+}
+
 static inline void sor_point(const double *b, double *x, i64 nx, i64 j, i64 i, double alpha, double beta,
                              double h2)
 {
@@ -525,6 +546,7 @@ typedef struct {
     double *xw[MAXLEV], *bw[MAXLEV], *rw[MAXLEV];
     double eps;
     int ordering;          /* 0 lexicographic (reference), 1 red-black */
+    double jacobi_omega;   /* 1 = the reference's sweep */
     int fix_coarse_ascent; /* 0: reference loop bounds (:302); 1: the ascent also reaches xw[0] */
     int max_cycles;
     int it;
@@ -548,6 +570,7 @@ void *orc_global_create(i64 ny0, i64 nx0, int n_para, double h0, double eps, int
     global_t *s = (global_t *)calloc(1, sizeof(global_t));
     s->n_para = n_para, s->eps = eps, s->ordering = ordering, s->fix_coarse_ascent = fix_coarse_ascent;
     s->max_cycles = MAXCYC;
+    s->jacobi_omega = 1.0;
     for (int l = 0; l < n_para; l++) {
         s->ny[l] = ((ny0 - 1) >> l) + 1, s->nx[l] = ((nx0 - 1) >> l) + 1;
         s->h[l] = h0 * (double)((i64)1 << l);
@@ -582,6 +605,7 @@ void orc_global_destroy(void *hd)
 }
 
 void orc_global_set_max_cycles(void *hd, int m) { ((global_t *)hd)->max_cycles = m; }
+void orc_global_set_jacobi_omega(void *hd, double omega) { ((global_t *)hd)->jacobi_omega = omega; }
 int orc_global_num_whole_levels(void *hd) { return ((global_t *)hd)->nwl; }
 
 /* which: 0 x, 1 b, 2 r (Jacobi levels); 3 xw, 4 bw, 5 rw (coarse-smoother levels) */
@@ -604,8 +628,12 @@ static void g_smooth(global_t *s, const double *b, double *x, double h, double *
                      int want_r)
 {
     memcpy(s->tmp, x, (size_t)(ny * nx) * sizeof(double));
-    for (int k = 0; k < iterations; k++)
-        orc_smooth_sweep_jacobi(b, x, s->tmp, ny, nx, h);
+    for (int k = 0; k < iterations; k++) {
+        if (s->jacobi_omega == 1.0)
+            orc_smooth_sweep_jacobi(b, x, s->tmp, ny, nx, h);
+        else
+            orc_smooth_sweep_jacobi_damped(b, x, s->tmp, ny, nx, h, s->jacobi_omega);
+    }
     if (want_r)
         orc_residual(r, x, b, ny, nx, h);
 }

@@ -63,17 +63,17 @@ class OracleOps:
 
     # ------------------------------------------------------------------ kernels
     @_batched
-    def jacobi(self, b, x, xo, nx, j0, j1, h, finest=False):
+    def jacobi(self, b, x, xo, nx, j0, j1, h, finest=False, omega=1.0):
         xs = np.ascontiguousarray(x.numpy()[j0 - 1 : j1 + 1, :nx])
         bs = np.ascontiguousarray(b.numpy()[j0 - 1 : j1 + 1, :nx])
-        oracle.smooth_sweep_jacobi(bs, xs, xs.copy(), h)
+        oracle.smooth_sweep_jacobi(bs, xs, xs.copy(), h, omega)
         xo.numpy()[j0:j1, 1 : nx - 1] = xs[1:-1, 1:-1]
 
     @_batched
-    def jacobi_from_zero(self, b, xo, nx, j0, j1, h, finest=False):
+    def jacobi_from_zero(self, b, xo, nx, j0, j1, h, finest=False, omega=1.0):
         bs = np.ascontiguousarray(b.numpy()[j0 - 1 : j1 + 1, :nx])
         xs = np.zeros_like(bs)
-        oracle.smooth_sweep_jacobi(bs, xs, xs.copy(), h)
+        oracle.smooth_sweep_jacobi(bs, xs, xs.copy(), h, omega)
         xo.numpy()[j0:j1, 1 : nx - 1] = xs[1:-1, 1:-1]
 
     @_batched
@@ -123,7 +123,7 @@ class OracleOps:
 
     @_batched
     def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
-                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0):
+                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0, omega=1.0):
         """The fused pass as the sequence it stands for: prolong_add (before the first sweep, or after
         `prolong_after` sweeps from zero), `sweeps` Jacobi sweeps, residual (rows between the fixed rows
         are the interior; only rows j0..j1-1 are written back)."""
@@ -138,7 +138,7 @@ class OracleOps:
             if k == sweeps:
                 break
             nxt = cur.clone()
-            self.jacobi(b, cur, nxt, nx, lo, hi, h)
+            self.jacobi(b, cur, nxt, nx, lo, hi, h, omega=omega)
             cur = nxt
         if x_out is not None:
             x_out[j0:j1] = cur[j0:j1]

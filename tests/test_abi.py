@@ -37,9 +37,9 @@ def test_argument_checks_run_before_any_gpu_call():
     """Shape validation happens on the host, so it can be exercised without a GPU."""
     from multigrid_amd import _lib
     L = _lib.lib()
-    assert L.mg_jacobi(None, None, None, 10, 10, 10, 1, 9, 1.0, 1, 0, 0, None) != 0
+    assert L.mg_jacobi(None, None, None, 10, 10, 10, 1, 9, 1.0, 1.0, 1, 0, 0, None) != 0
     assert b"null" in L.mg_last_error()
-    assert L.mg_jacobi(8, 16, 24, 10, 10, 4, 1, 9, 1.0, 1, 0, 0, None) != 0
+    assert L.mg_jacobi(8, 16, 24, 10, 10, 4, 1, 9, 1.0, 1.0, 1, 0, 0, None) != 0
     assert b"ld" in L.mg_last_error()
     assert L.mg_restrict(8, 10, 10, 10, 16, 10, 10, 10, 1, 9, 0, 0, 1, 0, 0, None) != 0
     assert L.mg_sor(8, 16, None, 2, 2, 2, 1.0, 1, 1, 0, 1, 0, None) != 0

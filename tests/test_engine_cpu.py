@@ -64,6 +64,26 @@ def test_single_rank_equals_global_oracle(gny, gnx, n_para, ordering, fused):
         assert np.array_equal(eng.rw[k].numpy()[:, : W.nx], ref.array("rw", k))
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_damped_jacobi_equals_oracle_and_converges(fused):
+    """jacobi_omega < 1 (an option of this build, not of the reference): same values as the oracle's
+    damped schedule, and with the textbook ascent the cycle then converges on a right-hand side full
+    of the checkerboard mode, where the undamped sweep stalls."""
+    gny = gnx = 129
+    b = _rhs(gny, gnx, 5)
+    kw = dict(fix_coarse_ascent=True, jacobi_omega=0.8)
+    ref = oracle.GlobalSolver(gny, gnx, 3, 0.5, 0.0, "lexicographic", **kw)
+    ref.b[:] = b
+    ref.solve(ncycles=6)
+    eng, errs, x, r = _engine_run(gny, gnx, 3, 0.5, b, 1, 0, 6, fused=fused, **kw)
+    assert errs == ref.err_hist.tolist()
+    assert np.array_equal(x, ref.x) and np.array_equal(r, ref.r)
+    und = oracle.GlobalSolver(gny, gnx, 3, 0.5, 0.0, "lexicographic", fix_coarse_ascent=True)
+    und.b[:] = b
+    und.solve(ncycles=6)
+    assert ref.err_hist[-1] < 1e-4 * ref.err_hist[0] and und.err_hist[-1] > 0.05 * und.err_hist[0]
+
+
 def test_fix_coarse_ascent_and_ascent_residuals():
     gny = gnx = 129
     b = _rhs(gny, gnx, 3)

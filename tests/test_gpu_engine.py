@@ -251,6 +251,50 @@ def test_converged_solution_matches_direct_solve():
         eng.close()
 
 
+@pytest.mark.parametrize("gny,gnx,n_para", [(129, 129, 3), (1025, 1025, 4), (513, 2049, 5)], ids=str)
+@pytest.mark.parametrize("graph,recompute,fused", [(True, True, True), (False, False, True), (True, False, False)])
+def test_damped_jacobi_equals_oracle(gny, gnx, n_para, graph, recompute, fused):
+    """jacobi_omega = 0.8 (every sweep x + omega (t - x); an option of this build, the reference's omega
+    is 1): bit-identical to the oracle's damped schedule, fused or not, recomputed pre-smoothing or not."""
+    b = _rhs(gny, gnx, 2)
+    h = 0.37
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0, fix_coarse_ascent=True, jacobi_omega=0.8)
+    ref.b[:] = b
+    ref.solve(ncycles=4)
+    eng = _make(gny, gnx, n_para, h, 0.0, b, fix_coarse_ascent=True, jacobi_omega=0.8, use_graph=graph, fused=fused,
+                recompute_presmoothing=recompute, recompute_min_nx=0, recompute_min_blocks=0)
+    eng.presmooth()
+    errs = eng.cycles(4)
+    assert errs == ref.err_hist.tolist()
+    assert np.array_equal(_rows(eng, eng.x0), ref.x)
+    assert np.array_equal(_rows(eng, eng.r0), ref.r)
+    eng.close()
+
+
+def test_damped_textbook_cycle_converges_to_rounding_level():
+    """With damping and the textbook ascent the stop rule is met at a tolerance nine orders below the
+    right-hand side within 25 cycles, and the solution equals a sparse direct solve (the reference's
+    own schedule needs tens of thousands of cycles for that, see above)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    n, n_para = 6, 3
+    b0, h = vortex_rhs(n)
+    N = 2 ** (n + 1) + 1
+    b0[0] = b0[-1] = 0
+    b0[:, 0] = b0[:, -1] = 0
+    m = N - 2
+    T = sp.diags([np.ones(m - 1), -2 * np.ones(m), np.ones(m - 1)], [-1, 0, 1])
+    A = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))) / h ** 2
+    x_direct = np.zeros((N, N))
+    x_direct[1:-1, 1:-1] = spla.spsolve(A.tocsc(), b0[1:-1, 1:-1].ravel()).reshape(m, m)
+    eng = _make(N, N, n_para, h, 50 * 1e-9, b0, fix_coarse_ascent=True, jacobi_omega=0.8)
+    err = eng.solve()
+    assert err <= 50 * 1e-9 and eng.it <= 25 and not eng.diverged, (err, eng.it)
+    rel = np.linalg.norm(_rows(eng, eng.x0) - x_direct) / np.linalg.norm(x_direct)
+    assert rel < 1e-10, rel
+    eng.close()
+
+
 def test_rectangular_and_nan():
     """Rectangular grids work; a NaN in the right-hand side surfaces in the returned norm."""
     b = _rhs(129, 513, 5)

@@ -148,34 +148,36 @@ def test_stencils_vs_oracle(mm, L, shape, vec, unroll):
         L.check(L.lib().mg_set_tuning(b"unroll", 2))
 
 
-def test_jacobi_row_range_and_from_zero(L):
-    """Row-range launches touch only their rows; the from-zero sweep equals a sweep on x = 0."""
+@pytest.mark.parametrize("om", [1.0, 0.8])
+def test_jacobi_row_range_and_from_zero(L, om):
+    """Row-range launches touch only their rows; the from-zero sweep equals a sweep on x = 0.  om < 1: the
+    damped sweep x + om * (t - x) against the oracle's."""
     import torch
     rng = np.random.default_rng(5)
     ny, nx = 70, 300
     a, b = rng.standard_normal((ny, nx)), rng.standard_normal((ny, nx))
     h = 0.7
     ref, t = a.copy(), a.copy()
-    oracle.smooth_sweep_jacobi(b, ref, t, h)
+    oracle.smooth_sweep_jacobi(b, ref, t, h, om)
     da, db = padded(a), padded(b)
     out = padded(np.full((ny, nx), 7.0))
     ld = out.stride(0)
     st = torch.cuda.current_stream().cuda_stream
     lib = L.lib()
-    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 10, 33, h, 1, 0, 0, st))
+    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 10, 33, h, om, 1, 0, 0, st))
     o = out.cpu().numpy()
     assert np.array_equal(o[10:33, 1:-1], ref[10:33, 1:-1])
     o[10:33, 1:-1] = 7.0
     assert np.all(o == 7.0)
     # two launches covering disjoint row ranges == one full sweep
-    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 1, 10, h, 1, 0, 0, st))
-    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 10, ny - 1, h, 1, 0, 0, st))
+    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 1, 10, h, om, 1, 0, 0, st))
+    L.check(lib.mg_jacobi(db.data_ptr(), da.data_ptr(), out.data_ptr(), ny, nx, ld, 10, ny - 1, h, om, 1, 0, 0, st))
     assert np.array_equal(out.cpu().numpy()[1:-1, 1:-1], ref[1:-1, 1:-1])
     # from zero
     z, tz = np.zeros((ny, nx)), np.zeros((ny, nx))
-    oracle.smooth_sweep_jacobi(b, z, tz, h)
+    oracle.smooth_sweep_jacobi(b, z, tz, h, om)
     out2 = padded(np.zeros((ny, nx)))
-    L.check(lib.mg_jacobi_from_zero(db.data_ptr(), out2.data_ptr(), ny, nx, ld, 1, ny - 1, h, 1, 0, 0, st))
+    L.check(lib.mg_jacobi_from_zero(db.data_ptr(), out2.data_ptr(), ny, nx, ld, 1, ny - 1, h, om, 1, 0, 0, st))
     got = out2.cpu().numpy()
     assert np.array_equal(got, z)
     assert np.array_equal(np.signbit(got), np.signbit(z))
@@ -301,6 +303,7 @@ def test_sor_redblack_vs_oracle(mm, shape):
 
 
 def test_batched_kernels(L):
+    om = 1.0
     """nbatch > 1: every grid of the batch gets the single-grid result."""
     import torch
     rng = np.random.default_rng(21)
@@ -318,7 +321,7 @@ def test_batched_kernels(L):
     db, dx, do = dev(b), dev(x), dev(x)
     lib = L.lib()
     st = torch.cuda.current_stream().cuda_stream
-    L.check(lib.mg_jacobi(db.data_ptr(), dx.data_ptr(), do.data_ptr(), ny, nx, ld, 1, ny - 1, h, nb, stride, 0, st))
+    L.check(lib.mg_jacobi(db.data_ptr(), dx.data_ptr(), do.data_ptr(), ny, nx, ld, 1, ny - 1, h, om, nb, stride, 0, st))
     got = do.cpu().numpy()[:, :, :nx]
     for k in range(nb):
         ref, t = x[k].copy(), x[k].copy()
@@ -354,6 +357,7 @@ def test_batched_kernels(L):
 
 
 def test_error_behaviour(mm, L):
+    om = 1.0
     """Wrong dtype/rank -> TypeError (as the compiled reference module); bad shapes are rejected
     on the host before any launch."""
     import torch
@@ -375,9 +379,20 @@ def test_error_behaviour(mm, L):
     lib = L.lib()
     d = padded(a)
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.mg_jacobi(d.data_ptr(), d.data_ptr(), d.data_ptr(), 10, 10, 16, 1, 9, 1.0, 1, 0, 0, st) != 0
+    assert lib.mg_jacobi(d.data_ptr(), d.data_ptr(), d.data_ptr(), 10, 10, 16, 1, 9, 1.0, om, 1, 0, 0, st) != 0
     assert b"alias" in lib.mg_last_error()
-    assert lib.mg_jacobi(d.data_ptr(), d.data_ptr(), None, 10, 10, 16, 0, 9, 1.0, 1, 0, 0, st) != 0
+    assert lib.mg_jacobi(d.data_ptr(), d.data_ptr(), None, 10, 10, 16, 0, 9, 1.0, om, 1, 0, 0, st) != 0
+    d2 = torch.zeros((10, 16), dtype=torch.float64, device="cuda")
+    for bad in (0.0, 1.5, -0.8, float("nan")):  # the damping factor must lie in (0, 1]
+        assert lib.mg_jacobi(d.data_ptr(), d.data_ptr(), d2.data_ptr(), 10, 10, 16, 1, 9, 1.0, bad, 1, 0, 0, st) != 0
+        assert lib.mg_jacobi_from_zero(d.data_ptr(), d2.data_ptr(), 10, 10, 16, 1, 9, 1.0, bad, 1, 0, 0, st) != 0
+        assert lib.mg_smooth_fused(d.data_ptr(), d.data_ptr(), d2.data_ptr(), None, None, 10, 10, 16, 0, 0, 0, 1, 9, 0, 9, 0, 3, 0,
+                                   1.0, bad, None, 1, 0, 0, st) != 0
+    # damped passes exist for 1, 3 and 6 sweeps
+    assert lib.mg_smooth_fused(d.data_ptr(), d.data_ptr(), d2.data_ptr(), None, None, 10, 10, 16, 0, 0, 0, 1, 9, 0, 9, 0, 2, 0,
+                               1.0, 0.8, None, 1, 0, 0, st) != 0
+    assert lib.mg_smooth_fused(d.data_ptr(), d.data_ptr(), d2.data_ptr(), None, None, 10, 10, 16, 0, 0, 0, 1, 9, 0, 9, 0, 3, 0,
+                               1.0, 0.8, None, 1, 0, 0, st) == 0
     # rank outside 0..3: the reference copies nothing
     o = np.full((5, 5), 3.0)
     mm.split(a, o, 7)
@@ -394,11 +409,14 @@ FUSED_SHAPES = [(9, 9), (40, 121), (70, 249), (66, 250), (300, 257), (130, 1000)
 @pytest.mark.parametrize("mode", ["plain", "zero", "prolong"])
 @pytest.mark.parametrize("resid", [False, True])
 @pytest.mark.parametrize("unroll", [1, 2])
-def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unroll):
+@pytest.mark.parametrize("om", [1.0, 0.8])
+def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unroll, om):
     """mg_smooth_fused == mg_prolong_add, `sweeps` x mg_jacobi, mg_residual, bit for bit (and hence
     == the oracle, which the separate kernels are checked against above)."""
     import ctypes as C
     import torch
+    if om != 1.0 and sweeps not in (1, 3, 6):
+        pytest.skip("damped passes are built for the depths of the V-cycle")
     ny, nx = shape
     rng = np.random.default_rng(ny * 131 + nx + sweeps)
     h = 0.3
@@ -428,7 +446,7 @@ def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unrol
                                    0, -1, 1, 0, 0, st))
     oth = padded(cur.cpu().numpy())
     for _ in range(sweeps):
-        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, j0, j1, h, 1, 0, 0, st))
+        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, j0, j1, h, om, 1, 0, 0, st))
         cur, oth = oth, cur
     slots = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
     r_ref = padded(r0)
@@ -444,7 +462,7 @@ def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unrol
     L.check(lib.mg_smooth_fused(db.data_ptr(), None if mode == "zero" else dx.data_ptr(), out.data_ptr(),
                                 rr.data_ptr() if resid else None, dc.data_ptr() if prolong else None, ny, nx, ld,
                                 cny if prolong else 0, cnx if prolong else 0, dc.stride(0) if prolong else 0, j0, j1,
-                                flo, fhi, -1, sweeps, 0, h, slots.data_ptr() if resid else None, 1, 0, 0, st))
+                                flo, fhi, -1, sweeps, 0, h, om, slots.data_ptr() if resid else None, 1, 0, 0, st))
     assert np.array_equal(out.cpu().numpy(), cur.cpu().numpy())
     if resid:
         nrm = C.c_double()
@@ -455,6 +473,7 @@ def test_fused_pass_equals_separate_kernels(L, shape, sweeps, mode, resid, unrol
 
 
 def test_fused_pass_partial_rows(L):
+    om = 1.0
     """Producing only rows [j0, j1) needs valid input on D more rows each side and leaves the rest alone."""
     import torch
     rng = np.random.default_rng(77)
@@ -466,11 +485,11 @@ def test_fused_pass_partial_rows(L):
     ld = dx.stride(0)
     cur, oth = padded(x), padded(x)
     for _ in range(3):
-        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, 1, ny - 1, h, 1, 0, 0, st))
+        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, 1, ny - 1, h, om, 1, 0, 0, st))
         cur, oth = oth, cur
     out = padded(np.full((ny, nx), 5.0))
     L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), out.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, 60, 131, 0,
-                                ny - 1, 0, 3, 0, h, None, 1, 0, 0, st))
+                                ny - 1, 0, 3, 0, h, om, None, 1, 0, 0, st))
     got, ref = out.cpu().numpy(), cur.cpu().numpy()
     assert np.array_equal(got[60:131], ref[60:131])
     got[60:131] = 5.0
@@ -481,7 +500,8 @@ def test_fused_pass_partial_rows(L):
 @pytest.mark.parametrize("sweeps", [1, 3, 6])
 @pytest.mark.parametrize("mode", ["plain", "zero", "prolong"])
 @pytest.mark.parametrize("store_r,waves", [(True, 4), (False, 4), (False, 2), (True, 1)])
-def test_fused_restriction_equals_separate_kernels(L, shape, sweeps, mode, store_r, waves):
+@pytest.mark.parametrize("om", [1.0, 0.8])
+def test_fused_restriction_equals_separate_kernels(L, shape, sweeps, mode, store_r, waves, om):
     """mg_smooth_fused_restrict == mg_smooth_fused followed by mg_restrict, bit for bit, whether or
     not the residual itself is stored, for every number of column strips per workgroup."""
     import ctypes as C
@@ -519,13 +539,13 @@ def _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r):
     # separate: fused smoothing + residual, then the restriction kernel
     o1, r1, cb1 = padded(x), padded(z), padded(zc)
     s1 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
-    L.check(lib.mg_smooth_fused(*args, o1.data_ptr(), r1.data_ptr(), *cargs, 0, h, s1.data_ptr(), 1, 0, 0, st))
+    L.check(lib.mg_smooth_fused(*args, o1.data_ptr(), r1.data_ptr(), *cargs, 0, h, om, s1.data_ptr(), 1, 0, 0, st))
     L.check(lib.mg_restrict(r1.data_ptr(), ny, nx, ld, cb1.data_ptr(), cny, cnx, cb1.stride(0), 2, cny - 1, 0, -1, 1, 0, 0,
                             st))
     # fused
     o2, r2, cb2 = padded(x), padded(z), padded(zc)
     s2 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
-    L.check(lib.mg_smooth_fused_restrict(*args, o2.data_ptr(), r2.data_ptr() if store_r else None, *cargs, h, s2.data_ptr(),
+    L.check(lib.mg_smooth_fused_restrict(*args, o2.data_ptr(), r2.data_ptr() if store_r else None, *cargs, h, om, s2.data_ptr(),
                                          cb2.data_ptr(), cny, cnx, cb2.stride(0), 2, cny - 1, 1, 0, 0, 0, st))
     assert np.array_equal(o2.cpu().numpy(), o1.cpu().numpy())
     assert np.array_equal(cb2.cpu().numpy(), cb1.cpu().numpy())
@@ -542,7 +562,8 @@ def _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r):
 @pytest.mark.parametrize("shape", [(10, 9), (18, 17), (34, 33), (40, 121), (70, 249), (300, 257), (130, 1001), (600, 2051),
                                    (258, 4099)], ids=str)
 @pytest.mark.parametrize("resid", [False, True])
-def test_fused_presmoothing_recomputed(L, shape, resid):
+@pytest.mark.parametrize("om", [1.0, 0.8])
+def test_fused_presmoothing_recomputed(L, shape, resid, om):
     """prolong_after = 3, sweeps = 9: 3 sweeps from x = 0, += P(c), 6 sweeps [, residual] in one pass ==
     the separate kernels; and the descent pass that stores no x produces the same coarse right-hand
     side and norm as the one that does."""
@@ -568,7 +589,7 @@ def test_fused_presmoothing_recomputed(L, shape, resid):
             L.check(lib.mg_prolong_add(dc.data_ptr(), cny, cnx, dc.stride(0), cur.data_ptr(), ny, nx, ld, j0, j1, 1, nx - 2,
                                        0, -1, 1, 0, 0, st))
             oth.copy_(cur)
-        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, j0, j1, h, 1, 0, 0, st))
+        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, j0, j1, h, om, 1, 0, 0, st))
         cur, oth = oth, cur
     r_ref = padded(z)
     s1 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
@@ -578,7 +599,7 @@ def test_fused_presmoothing_recomputed(L, shape, resid):
     out, rr = padded(z), padded(z)
     s2 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
     L.check(lib.mg_smooth_fused(db.data_ptr(), None, out.data_ptr(), rr.data_ptr() if resid else None, dc.data_ptr(), ny, nx,
-                                ld, cny, cnx, dc.stride(0), j0, j1, flo, fhi, -1, 9, 3, h, s2.data_ptr() if resid else None,
+                                ld, cny, cnx, dc.stride(0), j0, j1, flo, fhi, -1, 9, 3, h, om, s2.data_ptr() if resid else None,
                                 1, 0, 0, st))
     assert np.array_equal(out.cpu().numpy(), cur.cpu().numpy())
     if resid:
@@ -592,12 +613,12 @@ def test_fused_presmoothing_recomputed(L, shape, resid):
     o1, cb1, cb2 = padded(z), padded(zc), padded(zc)
     for xo, cb in ((o1, cb1), (None, cb2)):
         L.check(lib.mg_smooth_fused_restrict(db.data_ptr(), None, xo.data_ptr() if xo is not None else None, None, None, ny,
-                                             nx, ld, 0, 0, 0, j0, j1, flo, fhi, -1, 3, h, None, cb.data_ptr(), cny, cnx,
+                                             nx, ld, 0, 0, 0, j0, j1, flo, fhi, -1, 3, h, om, None, cb.data_ptr(), cny, cnx,
                                              cb.stride(0), 2, cny - 1, 1, 0, 0, 0, st))
     assert np.array_equal(cb1.cpu().numpy(), cb2.cpu().numpy())
     assert cb1.cpu().numpy().any()
     # rejected combinations
     assert lib.mg_smooth_fused(db.data_ptr(), None, out.data_ptr(), None, dc.data_ptr(), ny, nx, ld, cny, cnx, dc.stride(0),
-                               j0, j1, flo, fhi, -1, 6, 3, h, None, 1, 0, 0, st) != 0
+                               j0, j1, flo, fhi, -1, 6, 3, h, om, None, 1, 0, 0, st) != 0
     assert lib.mg_smooth_fused(db.data_ptr(), out.data_ptr(), rr.data_ptr(), None, dc.data_ptr(), ny, nx, ld, cny, cnx,
-                               dc.stride(0), j0, j1, flo, fhi, -1, 9, 3, h, None, 1, 0, 0, st) != 0
+                               dc.stride(0), j0, j1, flo, fhi, -1, 9, 3, h, om, None, 1, 0, 0, st) != 0
