@@ -508,12 +508,12 @@ def test_fused_restriction_equals_separate_kernels(L, shape, sweeps, mode, store
     import torch
     L.check(L.lib().mg_set_tuning(b"fused_waves", waves))
     try:
-        _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r)
+        _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r, om)
     finally:
         L.check(L.lib().mg_set_tuning(b"fused_waves", 4))
 
 
-def _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r):
+def _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r, om):
     ny, nx = shape
     rng = np.random.default_rng(ny + 7 * nx + sweeps)
     h = 0.3
