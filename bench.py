@@ -233,9 +233,9 @@ def main():
         # launches overwrite b_1 with what the next cycle would compute anyway; x ping-pongs.
         pass_ms = timed(lambda k: ops.smooth_fused(eng.b[0], xs[k & 1], xs[1 - (k & 1)], None, crs, L0.nx, L1.nx,
                                                    L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, L0.h, eng.norm,
-                                                   eng.b[1], L1.nx, L1.t0, L1.t1))
-        dom_name = ("mg_fused_kernel<6, true, false, true, true, 1, 0, false> (finest level: prolongation + 6 Jacobi sweeps + "
-                    "residual + max-norm + restriction)")
+                                                   eng.b[1], L1.nx, L1.t0, L1.t1, omega=args.jacobi_omega))
+        dom_name = (f"mg_fused_kernel<6, true, false, true, true, 1, 0, {'false' if args.jacobi_omega == 1.0 else 'true'}> "
+                    "(finest level: prolongation + 6 Jacobi sweeps + residual + max-norm + restriction)")
         dom_ms = pass_ms
         alg_bpp = 18 + 6 * 24 + 24 + 10  # per-operation compulsory bytes x the operations this launch performs
         own_bpp = 8 + 2 + 8 + 8 + 2      # what the pass itself must move: R x, R coarse x, R b, W x, W coarse b
