@@ -2,7 +2,8 @@
 device, so the calls the multi-GPU engine makes -- a batch of row sends/receives, the all-gather of
 whole rows into a padded array, the integer MAX-reduction of the norm slots -- are issued here with
 the rank as its own neighbour, on views shaped like the engine's.  Checks that the backend accepts
-the tensors as they are (views, dtypes) and moves the right bytes.  Marked gpu."""
+the tensors as they are (views, dtypes) and moves the right bytes, and that the engine's hipGraph
+capture and replay work in a process that holds an RCCL communicator.  Marked gpu."""
 import os
 import socket
 
@@ -65,8 +66,26 @@ def _worker(port, q):
         ops.stream.synchronize()
         per_round = (time.perf_counter() - t0) / 50
         ops.end()
+        # capturing and replaying the cycle graphs while the RCCL communicator and its helper threads are alive
+        import numpy as np
+        from multigrid_amd.engine import SlabMultigrid
+        rng = np.random.default_rng(0)
+        b = rng.standard_normal((257, 257))
+        b[0] = b[-1] = 0
+        b[:, 0] = b[:, -1] = 0
+        runs = []
+        for graph in (True, False):
+            eng = SlabMultigrid(257, 257, 3, 0.3, 0.0, world=1, rank=0, use_graph=graph, eager_dead_levels=True)
+            eng.set_b_rows(torch.from_numpy(b).cuda())
+            eng.presmooth()
+            errs = eng.cycles(3)
+            comm.run(batch)  # communication between graph launches
+            errs += eng.cycles(2)
+            runs.append((errs, eng.local_rows(eng.x0).cpu().numpy()))
+            eng.close()
+        graphs_ok = runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
         ok = (bool(torch.equal(x, want)), bool(torch.equal(out[2:2 + rows], inp)), bool(out[:2].eq(0).all() and out[2 + rows:].eq(0).all()),
-              bool(torch.equal(slots, before)))
+              bool(torch.equal(slots, before)), graphs_ok)
         q.put((ok, per_round))
         dist.barrier()
     finally:
@@ -86,5 +105,5 @@ def test_slabcomm_direct_branch_on_one_rank_rccl_group():
         if p.is_alive():
             p.kill()
     print(f"one exchange round on a one-rank RCCL group: {per_round * 1e6:.0f} us")
-    assert ok == (True, True, True, True)
+    assert ok == (True, True, True, True, True)
     assert p.exitcode == 0
