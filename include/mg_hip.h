@@ -224,6 +224,61 @@ int mg_graph_end(void *stream, void **graph_exec_out);
 int mg_graph_launch(void *graph_exec, void *stream);
 int mg_graph_destroy(void *graph_exec);
 
+/*
+ * The whole solver behind a handle: Multigrid.__init__ / Multigrid.solve of
+ * core/parallel_multigrid.py:153-348 on the undecomposed (gny x gnx) grid, boundary included, on the
+ * current device, for callers that do not go through the Python engine.  The library owns the
+ * device arrays of every level (hipMalloc at create, hipFree at destroy) and its own streams; all
+ * calls of one handle must come from one thread at a time, with the device it was created on
+ * current.  Results equal the reference's schedule on the global grid bit for bit (the Python
+ * engine multigrid_amd.engine.SlabMultigrid on one rank issues the same passes).
+ *
+ *   mg_solver_create   level layout of __init__ (:182-219): n_para Jacobi levels of
+ *                      ((gny-1)>>l)+1 x ((gnx-1)>>l)+1 points with mesh width h0*2^l, then
+ *                      whole-domain SSOR levels down to 3 points per side; gny-1 and gnx-1 must be
+ *                      divisible by 2^n_para with at least 2 cells left.  All arrays start at zero.
+ *   flags              MG_SOLVER_FIX_COARSE_ASCENT  the ascent through the whole-domain levels
+ *                                                   reaches the first one (the reference's
+ *                                                   range(2, ..) at :302 stops one short)
+ *                      MG_SOLVER_REDBLACK           red-black instead of lexicographic SSOR
+ *                      MG_SOLVER_NO_GRAPH           launch kernel by kernel instead of replaying a
+ *                                                   hipGraph per cycle
+ *                      MG_SOLVER_LAZY_DEAD_LEVELS   skip the whole-domain levels below the first,
+ *                                                   which nothing reads under the reference's loop
+ *                                                   bounds (ignored with FIX_COARSE_ASCENT)
+ *   mg_solver_set      "jacobi_omega" (0 < w <= 1, 1 = the reference's sweep), "max_cycles"
+ *                      (default 100, :270), "recompute_min_nx" / "recompute_min_blocks" (size from
+ *                      which a coarse level recomputes its pre-smoothing instead of storing it)
+ *   mg_solver_upload   finest-level b (MG_SOLVER_B) or x (MG_SOLVER_X: initial guess and Dirichlet
+ *                      boundary values) from a host or device array of gny rows, src_ld apart
+ *   mg_solver_solve    solve() (:232-348): one sweep + residual, then V-cycles until max|r| <= eps,
+ *                      the 1.1x divergence latch trips (:337-340) or max_cycles ran; returns the
+ *                      cycle count (the reference's .it) and the last max|r|
+ *   mg_solver_presmooth / mg_solver_cycles   the opening sweep (:264-266) and exactly k cycles
+ *                      without stop test, max|r| after each into errs[k] (may be NULL)
+ *   mg_solver_history  max|r| after each cycle of the last mg_solver_solve, and whether the latch
+ *                      tripped; *count receives the number of cycles
+ *   mg_solver_download / mg_solver_array   any level's array to host memory / as a device pointer
+ *                      (valid until destroy; x of the finest level moves between two arrays, ask
+ *                      again after every solve).  MG_SOLVER_R exists on the finest level only.
+ */
+typedef struct mg_solver mg_solver;
+#define MG_SOLVER_FIX_COARSE_ASCENT 1
+#define MG_SOLVER_REDBLACK 2
+#define MG_SOLVER_NO_GRAPH 4
+#define MG_SOLVER_LAZY_DEAD_LEVELS 8
+enum { MG_SOLVER_X = 0, MG_SOLVER_B = 1, MG_SOLVER_R = 2, MG_SOLVER_XW = 3, MG_SOLVER_BW = 4, MG_SOLVER_RW = 5 };
+int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0, int flags, mg_solver **out);
+int mg_solver_destroy(mg_solver *s);
+int mg_solver_set(mg_solver *s, const char *key, double value);
+int mg_solver_upload(mg_solver *s, int which, const double *src, int64_t src_ld);
+int mg_solver_download(mg_solver *s, int which, int level, double *dst, int64_t dst_ld);
+int mg_solver_array(mg_solver *s, int which, int level, double **device_ptr, int64_t *ny, int64_t *nx, int64_t *ld);
+int mg_solver_presmooth(mg_solver *s);
+int mg_solver_cycles(mg_solver *s, int k, double *errs);
+int mg_solver_solve(mg_solver *s, double eps, int *it_out, double *err_out);
+int mg_solver_history(mg_solver *s, double *errs, int capacity, int *count, int *diverged);
+
 #ifdef __cplusplus
 }
 #endif

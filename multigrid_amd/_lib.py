@@ -53,7 +53,19 @@ SIGNATURES = {
     "mg_graph_end": ([_p, C.POINTER(_p)], _n),
     "mg_graph_launch": ([_p, _p], _n),
     "mg_graph_destroy": ([_p], _n),
+    "mg_solver_create": ([_i, _i, _n, _d, _n, C.POINTER(_p)], _n),
+    "mg_solver_destroy": ([_p], _n),
+    "mg_solver_set": ([_p, C.c_char_p, _d], _n),
+    "mg_solver_upload": ([_p, _n, _p, _i], _n),
+    "mg_solver_download": ([_p, _n, _n, _p, _i], _n),
+    "mg_solver_array": ([_p, _n, _n, C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _n),
+    "mg_solver_presmooth": ([_p], _n),
+    "mg_solver_cycles": ([_p, _n, C.POINTER(_d)], _n),
+    "mg_solver_solve": ([_p, _d, C.POINTER(_n), C.POINTER(_d)], _n),
+    "mg_solver_history": ([_p, C.POINTER(_d), _n, C.POINTER(_n), C.POINTER(_n)], _n),
 }
+SOLVER_FIX_COARSE_ASCENT, SOLVER_REDBLACK, SOLVER_NO_GRAPH, SOLVER_LAZY_DEAD_LEVELS = 1, 2, 4, 8
+SOLVER_ARRAYS = {"x": 0, "b": 1, "r": 2, "xw": 3, "bw": 4, "rw": 5}
 
 
 def lib():
@@ -65,6 +77,10 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP kernels are not built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C multigrid_amd/csrc`)"
             )
+        # torch ships its own HIP/HSA runtime libraries; whichever copy is loaded first serves the whole
+        # process, and a second copy initialised beside it finds no GPU.  Loading torch first makes the
+        # library bind to the runtime torch uses, whatever the caller imports later.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (args, res) in SIGNATURES.items():
             f = getattr(L, name)

@@ -1,0 +1,489 @@
+// The V-cycle solver behind a C handle: Multigrid.__init__/solve() of the reference
+// (core/parallel_multigrid.py:153-348) on the undecomposed grid of ONE GPU, for callers that do not
+// go through Python.  The library owns the device arrays of every level; the caller hands host (or
+// device) arrays over with mg_solver_upload / reads them back with mg_solver_download.
+//
+// The schedule is the one of the package's slab engine on one rank: every smoothing call is one fused
+// pass (mg_smooth_fused[_restrict]), the finest residual is restricted by the pass that computes it,
+// large coarse levels recompute their pre-smoothing inside the post-smoothing pass, the whole-domain
+// levels below the first (dead in the reference's loop bounds, :302) run on a second stream, and a
+// whole cycle is one hipGraph replay.  Values are those of the reference's schedule on the global
+// grid, bit for bit.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "mg_common.h"
+
+namespace {
+
+struct JLevel { // a Jacobi level: two x arrays (ping-pong), b; r on the finest only
+    i64 ny, nx, ld;
+    double h;
+    double *xa, *xb, *b, *r;
+    bool recompute; // pre-smoothing recomputed by the post-smoothing pass, x not stored on the way down
+};
+
+struct WLevel { // a whole-domain (SSOR) level
+    i64 ny, nx, ld;
+    double h;
+    double *x, *b, *r;
+};
+
+} // namespace
+
+struct mg_solver {
+    int device;
+    i64 gny, gnx;
+    int n_para;
+    double h0;
+    bool fix_coarse_ascent, use_graph, eager_dead;
+    int ordering;
+    double omega;
+    int max_cycles;
+    i64 recompute_min_nx, recompute_min_blocks;
+    std::vector<JLevel> lv;
+    std::vector<WLevel> wl;
+    std::vector<void *> allocs;
+    u64 *norm;
+    hipStream_t stream, side;
+    hipEvent_t fork, join;
+    hipGraphExec_t graphs[2][2]; // [array the finest x starts in][finest residual stored]
+    int graph_end_cur[2];
+    int cur0;      // which of (xa, xb) of level 0 holds x
+    bool r_stale;  // the finest residual array is older than x
+    int it;
+    bool diverged;
+    std::vector<double> hist;
+};
+
+namespace {
+
+const int N1 = 3, N2 = 6; // core/parallel_multigrid.py:255-256
+
+i64 pitch(i64 nx) { return (nx + 15) / 16 * 16; }
+
+int dev_alloc(mg_solver *s, double **p, i64 n)
+{
+    void *q = nullptr;
+    MG_HIP(hipMalloc(&q, (size_t)n * sizeof(double)));
+    s->allocs.push_back(q);
+    MG_HIP(hipMemsetAsync(q, 0, (size_t)n * sizeof(double), s->stream));
+    *p = (double *)q;
+    return 0;
+}
+
+int check_device(const mg_solver *s, const char *fn)
+{
+    MG_REQUIRE(s, "%s: null solver", fn);
+    int d = -1;
+    MG_HIP(hipGetDevice(&d));
+    MG_REQUIRE(d == s->device, "%s: the solver lives on device %d, the current device is %d", fn, s->device, d);
+    return 0;
+}
+
+void decide_recompute(mg_solver *s)
+{
+    for (int l = 0; l < s->n_para; ++l) {
+        JLevel &L = s->lv[l];
+        // the 9-deep pass pays with wider overlaps, which a level must be wide enough and have
+        // workgroups enough to absorb
+        const i64 strips = (L.nx + 107) / 108, blocks = ((strips + 3) / 4) * ((L.ny - 1 + 63) / 64);
+        L.recompute = l >= 1 && L.nx >= s->recompute_min_nx && blocks >= s->recompute_min_blocks;
+    }
+}
+
+// where the restricted residual of level l goes, and the coarse correction of level l comes from
+void coarse_of(mg_solver *s, int l, double **cb, i64 *cny, i64 *cnx, i64 *cld)
+{
+    if (l + 1 < s->n_para) {
+        JLevel &C = s->lv[l + 1];
+        *cb = C.b, *cny = C.ny, *cnx = C.nx, *cld = C.ld;
+    } else {
+        WLevel &C = s->wl[0];
+        *cb = C.b, *cny = C.ny, *cnx = C.nx, *cld = C.ld;
+    }
+}
+
+// smooth_parallel on the finest level (:100-114) with the prolongation in front (:322) and the
+// restriction of its residual behind (:273 of the next cycle): one pass
+int finest_pass(mg_solver *s, int sweeps, const double *crs, i64 cny, i64 cnx, i64 cld, bool want_norm, bool store_r)
+{
+    JLevel &L = s->lv[0];
+    double *xs[2] = {L.xa, L.xb};
+    double *cb;
+    i64 bny, bnx, bld;
+    coarse_of(s, 0, &cb, &bny, &bnx, &bld);
+    if (want_norm && mg_norm_reset((uint64_t *)s->norm, s->stream)) return 1;
+    if (mg_smooth_fused_restrict(L.b, xs[s->cur0], xs[1 - s->cur0], store_r ? L.r : nullptr, crs, L.ny, L.nx, L.ld, cny, cnx,
+                                 cld, 1, L.ny - 1, 0, L.ny - 1, 0, sweeps, L.h, s->omega,
+                                 want_norm ? (uint64_t *)s->norm : nullptr, cb, bny, bnx, bld, 1, bny - 1, 1, 0, 0, 0,
+                                 s->stream))
+        return 1;
+    s->cur0 = 1 - s->cur0;
+    s->r_stale = !store_r;
+    return 0;
+}
+
+// whole-domain levels below the first (:294-304)
+int tail_below(mg_solver *s, hipStream_t st)
+{
+    const int nw = (int)s->wl.size();
+    for (int i = 1; i < nw; ++i) {
+        WLevel &W = s->wl[i], &F = s->wl[i - 1];
+        if (mg_zero(W.x, W.ny * W.ld, st)) return 1;
+        if (mg_restrict(F.r, F.ny, F.nx, F.ld, W.b, W.ny, W.nx, W.ld, 1, W.ny - 1, 0, 0, 1, 0, 0, st)) return 1;
+        if (mg_sor(W.b, W.x, W.r, W.ny, W.nx, W.ld, W.h, N1, 1, s->ordering, 1, 0, st)) return 1;
+    }
+    // the reference's range(2, nw): the coarsest correction climbs to level 1, never into level 0
+    for (int i = 2; i < nw + (s->fix_coarse_ascent ? 1 : 0); ++i) {
+        WLevel &C = s->wl[nw - i + 1], &F = s->wl[nw - i];
+        if (mg_prolong_add(C.x, C.ny, C.nx, C.ld, F.x, F.ny, F.nx, F.ld, 0, F.ny, 1, F.nx - 2, 0, 0, 1, 0, 0, st)) return 1;
+        if (mg_sor(F.b, F.x, F.r, F.ny, F.nx, F.ld, F.h, N2, 1, s->ordering, 1, 0, st)) return 1;
+    }
+    return 0;
+}
+
+// the body of the loop at :270-347
+int cycle(mg_solver *s, bool store_r)
+{
+    const int n_para = s->n_para;
+    hipStream_t st = s->stream;
+    // descent: x = 0, N1 sweeps, residual, restriction (:274-289); b_1 came with the finest residual
+    for (int l = 1; l < n_para; ++l) {
+        JLevel &L = s->lv[l];
+        double *cb;
+        i64 bny, bnx, bld;
+        coarse_of(s, l, &cb, &bny, &bnx, &bld);
+        if (mg_smooth_fused_restrict(L.b, nullptr, L.recompute ? nullptr : L.xa, nullptr, nullptr, L.ny, L.nx, L.ld, 0, 0, 0,
+                                     1, L.ny - 1, 0, L.ny - 1, 0, N1, L.h, s->omega, nullptr, cb, bny, bnx, bld, 1, bny - 1, 1,
+                                     0, 0, 0, st))
+            return 1;
+    }
+    // first whole-domain level (:291-293)
+    WLevel &W0 = s->wl[0];
+    if (mg_zero(W0.x, W0.ny * W0.ld, st)) return 1;
+    if (mg_sor(W0.b, W0.x, W0.r, W0.ny, W0.nx, W0.ld, W0.h, N1, 1, s->ordering, 1, 0, st)) return 1;
+    bool forked = false;
+    if (s->fix_coarse_ascent) {
+        if (tail_below(s, st)) return 1;
+    } else if (s->eager_dead && s->wl.size() > 1) {
+        // nothing in the cycle reads these levels: beside the ascent, on the second stream
+        MG_HIP(hipEventRecord(s->fork, st));
+        MG_HIP(hipStreamWaitEvent(s->side, s->fork, 0));
+        if (tail_below(s, s->side)) return 1;
+        forked = true;
+    }
+    // ascent (:306-313): prolongation + N2 sweeps; the residuals of these levels are never read
+    const double *crs = W0.x;
+    i64 cny = W0.ny, cnx = W0.nx, cld = W0.ld;
+    for (int l = n_para - 1; l >= 1; --l) {
+        JLevel &L = s->lv[l];
+        if (L.recompute) {
+            if (mg_smooth_fused(L.b, nullptr, L.xa, nullptr, crs, L.ny, L.nx, L.ld, cny, cnx, cld, 1, L.ny - 1, 0, L.ny - 1, 0,
+                                N1 + N2, N1, L.h, s->omega, nullptr, 1, 0, 0, st))
+                return 1;
+            crs = L.xa;
+        } else {
+            if (mg_smooth_fused(L.b, L.xa, L.xb, nullptr, crs, L.ny, L.nx, L.ld, cny, cnx, cld, 1, L.ny - 1, 0, L.ny - 1, 0,
+                                N2, 0, L.h, s->omega, nullptr, 1, 0, 0, st))
+                return 1;
+            crs = L.xb;
+        }
+        cny = L.ny, cnx = L.nx, cld = L.ld;
+    }
+    if (finest_pass(s, N2, crs, cny, cnx, cld, true, store_r)) return 1;
+    if (forked) {
+        MG_HIP(hipEventRecord(s->join, s->side));
+        MG_HIP(hipStreamWaitEvent(st, s->join, 0));
+    }
+    return 0;
+}
+
+void drop_graphs(mg_solver *s)
+{
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            if (s->graphs[a][b]) {
+                (void)hipGraphExecDestroy(s->graphs[a][b]);
+                s->graphs[a][b] = nullptr;
+            }
+}
+
+int run_cycle(mg_solver *s, bool store_r)
+{
+    if (!s->use_graph) return cycle(s, store_r);
+    if (!s->graphs[s->cur0][store_r]) {
+        // capture every variant now (capturing records, it does not execute)
+        const int cur = s->cur0;
+        const bool stale = s->r_stale;
+        for (int start = 0; start < 2; ++start)
+            for (int sr = 0; sr < 2; ++sr) {
+                if (s->graphs[start][sr]) continue;
+                s->cur0 = start;
+                if (mg_graph_begin(s->stream)) return 1;
+                const int rc = cycle(s, sr != 0);
+                void *g = nullptr;
+                if (mg_graph_end(s->stream, &g) || rc) {
+                    s->cur0 = cur, s->r_stale = stale;
+                    if (g) mg_graph_destroy(g);
+                    return 1;
+                }
+                s->graphs[start][sr] = (hipGraphExec_t)g;
+                s->graph_end_cur[start] = s->cur0;
+            }
+        s->cur0 = cur, s->r_stale = stale;
+    }
+    if (mg_graph_launch(s->graphs[s->cur0][store_r], s->stream)) return 1;
+    s->cur0 = s->graph_end_cur[s->cur0];
+    s->r_stale = !store_r;
+    return 0;
+}
+
+int materialize_residual(mg_solver *s)
+{
+    if (!s->r_stale) return 0;
+    JLevel &L = s->lv[0];
+    if (mg_residual(L.r, s->cur0 ? L.xb : L.xa, L.b, L.ny, L.nx, L.ld, 1, L.ny - 1, L.h, nullptr, 1, 0, MG_FLAG_FINEST, s->stream))
+        return 1;
+    s->r_stale = false;
+    return 0;
+}
+
+int read_err(mg_solver *s, double *err) { return mg_norm_read((const uint64_t *)s->norm, err, s->stream); }
+
+} // namespace
+
+extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0, int flags, mg_solver **out)
+{
+    MG_REQUIRE(out, "mg_solver_create: null output");
+    *out = nullptr;
+    MG_REQUIRE(n_para >= 1 && n_para < 40, "mg_solver_create: n_para %d outside 1..39", n_para);
+    MG_REQUIRE(gny >= 3 && gnx >= 3 && gny < ((i64)1 << 30) && gnx < ((i64)1 << 30), "mg_solver_create: bad grid %lld x %lld",
+               (long long)gny, (long long)gnx);
+    MG_REQUIRE((gny - 1) % ((i64)1 << n_para) == 0 && (gnx - 1) % ((i64)1 << n_para) == 0,
+               "mg_solver_create: rows-1 (%lld) and columns-1 (%lld) must be divisible by 2^n_para = %lld", (long long)(gny - 1),
+               (long long)(gnx - 1), (long long)((i64)1 << n_para));
+    MG_REQUIRE(((gny - 1) >> n_para) >= 2 && ((gnx - 1) >> n_para) >= 2,
+               "mg_solver_create: the first whole-domain level needs at least 2 cells per side");
+    MG_REQUIRE(h0 > 0, "mg_solver_create: mesh width must be positive");
+    MG_REQUIRE((flags & ~(MG_SOLVER_FIX_COARSE_ASCENT | MG_SOLVER_REDBLACK | MG_SOLVER_NO_GRAPH | MG_SOLVER_LAZY_DEAD_LEVELS)) == 0,
+               "mg_solver_create: unknown flag bits in %d", flags);
+    mg_solver *s = new (std::nothrow) mg_solver();
+    MG_REQUIRE(s, "mg_solver_create: out of host memory");
+    s->gny = gny, s->gnx = gnx, s->n_para = n_para, s->h0 = h0;
+    s->fix_coarse_ascent = flags & MG_SOLVER_FIX_COARSE_ASCENT;
+    s->ordering = (flags & MG_SOLVER_REDBLACK) ? MG_SOR_REDBLACK : MG_SOR_LEXICOGRAPHIC;
+    s->use_graph = !(flags & MG_SOLVER_NO_GRAPH);
+    s->eager_dead = !(flags & MG_SOLVER_LAZY_DEAD_LEVELS);
+    s->omega = 1.0, s->max_cycles = 100; // :270
+    s->recompute_min_nx = 1024, s->recompute_min_blocks = 1024;
+    s->norm = nullptr, s->stream = s->side = nullptr, s->fork = s->join = nullptr;
+    s->cur0 = 0, s->r_stale = true, s->it = 0, s->diverged = false;
+    for (int a = 0; a < 2; ++a) s->graphs[a][0] = s->graphs[a][1] = nullptr, s->graph_end_cur[a] = 0;
+    int rc = 1;
+    do {
+        if (hipGetDevice(&s->device) != hipSuccess) { mg_set_error("mg_solver_create: no current device"); break; }
+        if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) {
+            mg_set_error("mg_solver_create: cannot create streams/events");
+            break;
+        }
+        bool ok = true;
+        for (int l = 0; l < n_para && ok; ++l) {
+            JLevel L;
+            L.ny = ((gny - 1) >> l) + 1, L.nx = ((gnx - 1) >> l) + 1, L.ld = pitch(L.nx);
+            L.h = h0 * (double)((i64)1 << l); // h_sb, :195
+            L.r = nullptr, L.recompute = false;
+            ok = !dev_alloc(s, &L.xa, L.ny * L.ld) && !dev_alloc(s, &L.xb, L.ny * L.ld) && !dev_alloc(s, &L.b, L.ny * L.ld);
+            if (ok && l == 0) ok = !dev_alloc(s, &L.r, L.ny * L.ld);
+            s->lv.push_back(L);
+        }
+        for (int l = n_para; ok; ++l) { // whole-domain levels down to 3 x 3 (:207-219)
+            const i64 my = (gny - 1) >> l, mx = (gnx - 1) >> l;
+            if (my < 2 || mx < 2 || (my << l) != gny - 1 || (mx << l) != gnx - 1) break;
+            WLevel W;
+            W.ny = my + 1, W.nx = mx + 1, W.ld = pitch(W.nx), W.h = h0 * (double)((i64)1 << l);
+            ok = !dev_alloc(s, &W.x, W.ny * W.ld) && !dev_alloc(s, &W.b, W.ny * W.ld) && !dev_alloc(s, &W.r, W.ny * W.ld);
+            s->wl.push_back(W);
+        }
+        if (!ok) break;
+        double *nrm = nullptr;
+        if (dev_alloc(s, &nrm, MG_NORM_SLOTS)) break;
+        s->norm = (u64 *)nrm;
+        if (hipStreamSynchronize(s->stream) != hipSuccess) { mg_set_error("mg_solver_create: device error"); break; }
+        decide_recompute(s);
+        rc = 0;
+    } while (0);
+    if (rc) {
+        mg_solver_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return 0;
+}
+
+extern "C" int mg_solver_destroy(mg_solver *s)
+{
+    if (!s) return 0;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->side) (void)hipStreamSynchronize(s->side);
+    drop_graphs(s);
+    for (void *p : s->allocs) (void)hipFree(p);
+    if (s->fork) (void)hipEventDestroy(s->fork);
+    if (s->join) (void)hipEventDestroy(s->join);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return 0;
+}
+
+extern "C" int mg_solver_set(mg_solver *s, const char *key, double value)
+{
+    if (check_device(s, "mg_solver_set")) return 1;
+    MG_REQUIRE(key, "mg_solver_set: null key");
+    if (!strcmp(key, "jacobi_omega")) {
+        MG_REQUIRE(value > 0 && value <= 1, "mg_solver_set: jacobi_omega %g outside (0, 1]", value);
+        s->omega = value;
+    } else if (!strcmp(key, "max_cycles")) {
+        MG_REQUIRE(value >= 1 && value <= 1e6, "mg_solver_set: max_cycles outside 1..1e6");
+        s->max_cycles = (int)value;
+        return 0; // the captured graphs do not depend on it
+    } else if (!strcmp(key, "recompute_min_nx")) {
+        s->recompute_min_nx = (i64)value;
+    } else if (!strcmp(key, "recompute_min_blocks")) {
+        s->recompute_min_blocks = (i64)value;
+    } else {
+        mg_set_error("mg_solver_set: unknown key '%s'", key);
+        return 1;
+    }
+    MG_HIP(hipStreamSynchronize(s->stream));
+    drop_graphs(s); // they were recorded with the old setting
+    decide_recompute(s);
+    return 0;
+}
+
+static int solver_array(mg_solver *s, int which, int level, double **p, i64 *ny, i64 *nx, i64 *ld)
+{
+    const int nj = s->n_para, nw = (int)s->wl.size();
+    if (which == MG_SOLVER_X || which == MG_SOLVER_B || which == MG_SOLVER_R) {
+        MG_REQUIRE(level >= 0 && level < nj, "mg_solver: Jacobi level %d outside 0..%d", level, nj - 1);
+        JLevel &L = s->lv[level];
+        MG_REQUIRE(which != MG_SOLVER_R || level == 0, "mg_solver: only the finest level keeps a residual array");
+        // after a cycle x of a coarse level is where its post-smoothing pass left it
+        *p = which == MG_SOLVER_B ? L.b : which == MG_SOLVER_R ? L.r
+             : level == 0 ? (s->cur0 ? L.xb : L.xa) : (L.recompute ? L.xa : L.xb);
+        *ny = L.ny, *nx = L.nx, *ld = L.ld;
+        return 0;
+    }
+    MG_REQUIRE(which == MG_SOLVER_XW || which == MG_SOLVER_BW || which == MG_SOLVER_RW, "mg_solver: unknown array id %d", which);
+    MG_REQUIRE(level >= 0 && level < nw, "mg_solver: whole-domain level %d outside 0..%d", level, nw - 1);
+    WLevel &W = s->wl[level];
+    *p = which == MG_SOLVER_XW ? W.x : which == MG_SOLVER_BW ? W.b : W.r;
+    *ny = W.ny, *nx = W.nx, *ld = W.ld;
+    return 0;
+}
+
+extern "C" int mg_solver_array(mg_solver *s, int which, int level, double **device_ptr, int64_t *ny, int64_t *nx,
+                               int64_t *ld)
+{
+    if (check_device(s, "mg_solver_array")) return 1;
+    MG_REQUIRE(device_ptr && ny && nx && ld, "mg_solver_array: null output");
+    if (which == MG_SOLVER_R && level == 0) {
+        if (materialize_residual(s)) return 1;
+    }
+    i64 a, b, c;
+    if (solver_array(s, which, level, device_ptr, &a, &b, &c)) return 1;
+    *ny = a, *nx = b, *ld = c;
+    MG_HIP(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int mg_solver_upload(mg_solver *s, int which, const double *src, int64_t src_ld)
+{
+    if (check_device(s, "mg_solver_upload")) return 1;
+    MG_REQUIRE(which == MG_SOLVER_X || which == MG_SOLVER_B, "mg_solver_upload: only x and b of the finest level can be set");
+    MG_REQUIRE(src && src_ld >= s->gnx, "mg_solver_upload: null source or src_ld < %lld", (long long)s->gnx);
+    JLevel &L = s->lv[0];
+    // both x arrays take the values, so that the Dirichlet cells agree whichever a pass writes
+    double *dst[2] = {which == MG_SOLVER_B ? L.b : L.xa, which == MG_SOLVER_B ? nullptr : L.xb};
+    for (double *d : dst)
+        if (d)
+            MG_HIP(hipMemcpy2DAsync(d, (size_t)L.ld * 8, src, (size_t)src_ld * 8, (size_t)L.nx * 8, (size_t)L.ny, hipMemcpyDefault,
+                                    s->stream));
+    MG_HIP(hipStreamSynchronize(s->stream));
+    s->r_stale = true;
+    return 0;
+}
+
+extern "C" int mg_solver_download(mg_solver *s, int which, int level, double *dst, int64_t dst_ld)
+{
+    if (check_device(s, "mg_solver_download")) return 1;
+    MG_REQUIRE(dst, "mg_solver_download: null destination");
+    if (which == MG_SOLVER_R && level == 0) {
+        if (materialize_residual(s)) return 1;
+    }
+    double *p;
+    i64 ny, nx, ld;
+    if (solver_array(s, which, level, &p, &ny, &nx, &ld)) return 1;
+    MG_REQUIRE(dst_ld >= nx, "mg_solver_download: dst_ld %lld < %lld columns", (long long)dst_ld, (long long)nx);
+    MG_HIP(hipMemcpy2DAsync(dst, (size_t)dst_ld * 8, p, (size_t)ld * 8, (size_t)nx * 8, (size_t)ny, hipMemcpyDefault, s->stream));
+    MG_HIP(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int mg_solver_presmooth(mg_solver *s)
+{
+    if (check_device(s, "mg_solver_presmooth")) return 1;
+    return finest_pass(s, 1, nullptr, 0, 0, 0, false, false); // :264-266
+}
+
+extern "C" int mg_solver_cycles(mg_solver *s, int k, double *errs)
+{
+    if (check_device(s, "mg_solver_cycles")) return 1;
+    MG_REQUIRE(k >= 0, "mg_solver_cycles: negative cycle count");
+    for (int c = 0; c < k; ++c) {
+        if (run_cycle(s, c == k - 1)) return 1; // the last pass leaves the residual array current
+        double e;
+        if (read_err(s, &e)) return 1;
+        if (errs) errs[c] = e;
+    }
+    return 0;
+}
+
+extern "C" int mg_solver_solve(mg_solver *s, double eps, int *it_out, double *err_out)
+{
+    if (check_device(s, "mg_solver_solve")) return 1;
+    s->it = 0, s->diverged = false;
+    s->hist.clear();
+    double err = 0.0, err_old = 100.0; // :258-259
+    if (mg_solver_presmooth(s)) return 1;
+    bool done = false;
+    while (!done && s->it < s->max_cycles) {
+        if (run_cycle(s, false)) return 1;
+        if (read_err(s, &err)) return 1;
+        s->hist.push_back(err);
+        if (err > err_old * 1.1) s->diverged = true; // :337-340
+        err_old = err;
+        done = !(err > eps && !s->diverged);
+        s->it += 1;
+    }
+    if (materialize_residual(s)) return 1;
+    MG_HIP(hipStreamSynchronize(s->stream));
+    if (it_out) *it_out = s->it;
+    if (err_out) *err_out = err;
+    return 0;
+}
+
+extern "C" int mg_solver_history(mg_solver *s, double *errs, int capacity, int *count, int *diverged)
+{
+    MG_REQUIRE(s, "mg_solver_history: null solver");
+    const int n = (int)s->hist.size();
+    for (int k = 0; k < n && k < capacity && errs; ++k) errs[k] = s->hist[k];
+    if (count) *count = n;
+    if (diverged) *diverged = s->diverged;
+    return 0;
+}
