@@ -557,7 +557,10 @@ static int launch_fused(FusedArgs a, hipStream_t st)
     constexpr int D = K + (RESID ? 1 : 0) + (RESTRICT ? 1 : 0), Dv = (D + 1) & ~1, W = 128 * U, STRIDE = W - 2 * Dv;
     constexpr int DK = K + (RESID ? 1 : 0); // window stages of the kernel: decides whether b lives in an LDS ring
     a.ntc = a.nx <= W ? 1 : (int)((a.nx - W + STRIDE - 1) / STRIDE) + 1;
-    const int wpb = g_fused_waves;
+    // column strips per workgroup: a narrow grid whose strip count does not fill the workgroups would leave
+    // wave slots empty (three strips of a 257-column grid in a 4-wave workgroup: a quarter of the slots)
+    int wpb = g_fused_waves;
+    while (wpb > 1 && a.ntc % wpb != 0 && a.ntc < 4 * wpb) wpb >>= 1;
     a.ncb = (a.ntc + wpb - 1) / wpb;
     int rpb = g_fused_rows;
     if (rpb <= 0) {
