@@ -36,7 +36,7 @@ import torch
 import torch.distributed as dist
 
 from .comm import SlabComm
-from .levels import make_plan, whole_level_fits_lds
+from .levels import choose_n_dist, make_plan, whole_level_fits_lds
 
 
 class SlabMultigrid:
@@ -46,7 +46,7 @@ class SlabMultigrid:
     def __init__(self, gny, gnx, n_para, h0, epsilon, *, ops=None, group=None, world=None, rank=None,
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
-                 store_residual_every_cycle=False, batch=None, dist_min_rows=2048, recompute_presmoothing=True,
+                 store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
                  recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0):
         if ops is None:
             from .ops import HipOps
@@ -63,15 +63,17 @@ class SlabMultigrid:
             # the recompute scheme: 10, rounded to 12 so that the halo of every level stays even);
             # one exchange per sweep needs one row, 2 keeps the halo even
             halo = (12 if recompute_presmoothing else 8) if self.fused else 2
-        # Jacobi levels 0 .. n_dist-1 are distributed, the others replicated on every rank.  A distributed
-        # level costs two exchange rounds per cycle (~0.1 ms of host time each on RCCL, plus the wire); a
-        # replicated one costs world x its own work.  With 2048 rows per rank (and as many columns) the two
-        # are about equal at 8 ranks; below that replication is cheaper.
+        # Jacobi levels 0 .. n_dist-1 are distributed, the others replicated on every rank: as many as the
+        # cost model of levels.choose_n_dist finds cheapest (exchange rounds against the all-gather of the
+        # first replicated level and the redundant work on the replicated ones), or, with dist_min_rows,
+        # every level with at least that many rows per rank.
         n_dist = n_para
         if world > 1:
-            H_ = halo
             R0 = (gny - 1) // world
-            n_dist = max(1, sum(1 for l in range(n_para) if (R0 >> l) >= max(dist_min_rows, H_)))
+            if dist_min_rows is None:
+                n_dist = choose_n_dist(gny, gnx, n_para, world, halo)
+            else:
+                n_dist = max(1, sum(1 for l in range(n_para) if (R0 >> l) >= max(dist_min_rows, halo)))
         self.n_dist = n_dist
         self.plan = make_plan(gny, gnx, n_para, world, rank, h0, halo, n_dist=n_dist)
         # the same grid on one rank, with the same halo depth: layout of the replicated levels; a

@@ -204,3 +204,24 @@ def choose_n_para(gny, gnx, world=1, at_least=1):
         if whole_level_fits_one_wave(plan.whole[0].ny, plan.whole[0].nx):
             return n_para
         n_para += 1
+
+
+def choose_n_dist(gny, gnx, n_para, world, halo, t_round=110e-6, gather_bw=100e9, stream_rate=4.5e12, bytes_per_point=36):
+    """How many of the Jacobi levels (the finest ones) to cut into slabs, by a cost model of one V-cycle:
+      * every distributed level costs two exchange rounds (t_round each: what a batch of row
+        sends/receives costs the host on RCCL; the rows themselves are a few hundred KB);
+      * the first replicated level's right-hand side is all-gathered: its bytes x (world-1)/world
+        arrive at every rank at gather_bw (xGMI is point-to-point: a ring moves ~one link's worth);
+      * every replicated level is computed by all ranks: its points x bytes_per_point at stream_rate.
+    Returns the k in 1..n_para with the least cost among those whose slabs hold at least `halo` rows."""
+    R0 = (gny - 1) // world
+    best, best_cost = 1, None
+    for k in range(1, n_para + 1):
+        if (R0 >> (k - 1)) < max(halo, 1):
+            break
+        pts = lambda l: (((gny - 1) >> l) + 1) * (((gnx - 1) >> l) + 1)  # noqa: E731
+        cost = 2 * k * t_round + 8 * pts(k) * (world - 1) / world / gather_bw
+        cost += sum(pts(l) for l in range(k, n_para)) * bytes_per_point / stream_rate
+        if best_cost is None or cost < best_cost:
+            best, best_cost = k, cost
+    return best

@@ -157,7 +157,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, dist_min_rows=256):
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, dist_min_rows=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -179,7 +179,7 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, di
 # dist_min_rows: Jacobi levels with fewer rows per rank are replicated on every rank instead of being
 # cut into slabs (8 = the halo depth: as many distributed levels as possible; 256 = the default, which
 # at these sizes leaves only the finest level distributed)
-@pytest.mark.parametrize("dist_min_rows", [8, 16, 256])
+@pytest.mark.parametrize("dist_min_rows", [8, 16, None])
 @pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 65, 65, 2, True), (2, 65, 33, 1, True), (2, 129, 65, 3, True), (2, 129, 65, 3, False),
                                                         (4, 129, 129, 3, True), (4, 257, 33, 2, True),
                                                         (4, 257, 33, 2, False)], ids=str)
@@ -248,3 +248,21 @@ def test_choose_n_para_keeps_the_whole_domain_level_in_lds():
             W0 = make_plan(gny, gnx, n_para - 1, world, 0).whole[0]
             assert not whole_level_fits_one_wave(W0.ny, W0.nx)
     assert choose_n_para(9, 9, 1, at_least=1) == 1
+
+
+def test_choose_n_dist_weighs_rounds_against_the_all_gather():
+    """The benchmark grids: levels are distributed until the all-gather of the next level's right-hand
+    side (and the redundant work below it) costs less than two more exchange rounds."""
+    from multigrid_amd.levels import choose_n_dist, choose_n_para
+    for world, want in ((2, 5), (4, 6), (8, 6)):
+        gny, gnx = world * 2 ** 15 + 1, 2 ** 15 + 1
+        n_para = choose_n_para(gny, gnx, world, at_least=8)
+        k = choose_n_dist(gny, gnx, n_para, world, 12)
+        assert k == want
+        assert ((gny - 1) // world >> (k - 1)) >= 12
+        # the gathered level is small: at most 32 MB
+        assert (((gny - 1) >> k) + 1) * (((gnx - 1) >> k) + 1) * 8 <= 32e6
+    assert choose_n_dist(257, 257, 3, 2, 12) == 1          # tiny grid: replicate everything below the finest
+    assert choose_n_dist(65, 65, 2, 4, 8) == 1             # slabs of 16 rows: the second level would hold fewer than the halo
+    # free exchanges and a slow gather: distribute every level whose slabs are tall enough
+    assert choose_n_dist(2 ** 15 + 1, 2 ** 15 + 1, 8, 2, 12, t_round=0.0, gather_bw=1e6) == 8
