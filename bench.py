@@ -226,14 +226,20 @@ def main():
               "algorithmic_bytes_per_launch": 24 * pts_launch, "achieved": 24 * pts_launch / (sweep_ms * 1e-3) / 1e9}
     single["frac"] = single["achieved"] / HBM_PEAK_GBPS
     if eng.fused:
-        crs = eng._xa[1] if n_para > 1 else (eng._xw0_pad if world == 1 else eng._corr)
+        # the correction and the restriction target as the cycle passes them: slab arrays of level 1, or, when
+        # level 1 is replicated on every rank, this rank's window of it and the slab that is all-gathered
+        rep1 = world > 1 and eng.n_dist == 1
+        crs = eng._xa[1] if n_para > 1 else eng._xw0_pad
+        if rep1:
+            crs = eng._window(crs, 1)
+        cb1 = eng._bslab if rep1 else eng.b[1]
         # exactly the launch the cycle makes on the finest level: prolongation + 6 sweeps + residual + max-norm
         # + full-weighting restriction of that residual into the next level's right-hand side (the residual
         # array itself is written once, when cycles() ends -- inside the timed region above).  The timed
         # launches overwrite b_1 with what the next cycle would compute anyway; x ping-pongs.
         pass_ms = timed(lambda k: ops.smooth_fused(eng.b[0], xs[k & 1], xs[1 - (k & 1)], None, crs, L0.nx, L1.nx,
                                                    L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, L0.h, eng.norm,
-                                                   eng.b[1], L1.nx, L1.t0, L1.t1, omega=args.jacobi_omega))
+                                                   cb1, L1.nx, L1.t0, L1.t1, omega=args.jacobi_omega))
         dom_name = (f"mg_fused_kernel<6, true, false, true, true, 1, 0, {'false' if args.jacobi_omega == 1.0 else 'true'}> "
                     "(finest level: prolongation + 6 Jacobi sweeps + residual + max-norm + restriction)")
         dom_ms = pass_ms
