@@ -96,3 +96,43 @@ def test_engine_equals_oracle_at_16385():
     assert np.array_equal(e.local_rows(e.x0).cpu().numpy(), ref.x)
     assert np.array_equal(e.local_rows(e.r0).cpu().numpy(), ref.r)
     e.close()
+
+
+def test_batch_of_1024_problems_equals_oracle_on_sampled_problems():
+    """The batched configuration at its full size (1024 independent 257 x 257 problems, four Jacobi levels):
+    every problem gets its own right-hand side (the vortex pattern scaled and shifted per problem); a sample
+    of problems is compared with the oracle bit for bit, the norm with the maximum over the sample's."""
+    import torch
+    from multigrid_amd.engine import SlabMultigrid
+    from tests.rhs import test_rhs
+    n, n_para, B = 7, 4, 1024
+    N = 2 ** (n + 1) + 1
+    b0, h = test_rhs(n)
+    b0[0] = b0[-1] = 0
+    b0[:, 0] = b0[:, -1] = 0
+    eng = SlabMultigrid(N, N, n_para, h, 0.0, batch=B, eager_dead_levels=True)
+    scale = torch.linspace(0.5, 1.5, B, dtype=torch.float64, device="cuda")
+    base = torch.from_numpy(b0).cuda()
+    rows = base.unsqueeze(0) * scale.view(B, 1, 1)
+    shift = torch.arange(B, device="cuda") % 64
+    for k in range(64):  # problem p sees the pattern rolled by p % 64 columns
+        sel = shift == k
+        rows[sel] = torch.roll(rows[sel], k, dims=2)
+    rows[:, :, 0] = 0
+    rows[:, :, -1] = 0
+    eng.set_b_rows(rows)
+    eng.presmooth()
+    errs = eng.cycles(3)
+    x = eng.local_rows(eng.x0)
+    r = eng.local_rows(eng.r0)
+    worst = 0.0
+    for p in (0, 1, 63, 64, 517, 1023):
+        ref = oracle.GlobalSolver(N, N, n_para, h, 0.0)
+        ref.b[:] = rows[p].cpu().numpy()
+        ref.solve(ncycles=3)
+        assert np.array_equal(x[p].cpu().numpy(), ref.x), p
+        assert np.array_equal(r[p].cpu().numpy(), ref.r), p
+        assert ref.err_hist[-1] <= errs[-1]
+        worst = max(worst, ref.err_hist[-1])
+    assert float(r.abs().max()) == errs[-1] >= worst
+    eng.close()
