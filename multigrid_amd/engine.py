@@ -187,6 +187,18 @@ class SlabMultigrid:
         self.ops.end()
         self._r0_stale = False
 
+    def problem_errors(self):
+        """max|r| of every problem of a batch after the last cycle (the stop rule itself looks at the
+        maximum over the batch): a (batch,) tensor on the device."""
+        if self.batch is None:
+            raise ValueError("problem_errors() is for batched solves")
+        r = self.local_rows(self.r0)
+        self.ops.begin()
+        with self.ops.ctx():
+            per = r.abs().amax(dim=(1, 2))
+        self.ops.end()  # the caller's stream sees the result
+        return per
+
     def owned_rows(self, level=0):
         """(first, last+1) local rows this rank owns, the global boundary rows included."""
         L = self.plan.levels[level]

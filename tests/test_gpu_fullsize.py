@@ -135,4 +135,7 @@ def test_batch_of_1024_problems_equals_oracle_on_sampled_problems():
         assert ref.err_hist[-1] <= errs[-1]
         worst = max(worst, ref.err_hist[-1])
     assert float(r.abs().max()) == errs[-1] >= worst
+    per = eng.problem_errors()
+    assert per.shape == (B,) and float(per.max()) == errs[-1]
+    assert float(per[517]) == float(r[517].abs().max())
     eng.close()
