@@ -106,6 +106,15 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
     constexpr int STRIDE = W - 2 * Dv;
     constexpr bool BL = D >= 5;                         // b ring in LDS
     constexpr int NG = BL ? (D + 1) / 3 + 1 : 1;        // groups of three row slots: rows i-1 .. i-D plus the rotation slack
+    // Scaled sweeps.  The reference's x' = 0.25 * (E + W + S + N - h2*b) costs six FP64 operations.  Keeping
+    // stage s's values multiplied by 4^s costs four: with z = 4^(s-1) x and hb = fl(h2*b),
+    //     z' = fma(-4^(s-1), hb, E_z + W_z + S_z + N_z) = 4^s x'
+    // bit for bit, because a power-of-two factor commutes with every rounding (the product inside the fma
+    // is exact) -- unless an intermediate leaves the normal range (|x| above 1e302 or below 1e-307), where
+    // the reference rounds a subnormal 0.25*t that the scaled form keeps.  The last stage multiplies by
+    // 4^-K.  Damped sweeps need the true values and keep the plain form.
+    constexpr bool SC = !DAMPED;
+    constexpr bool HB = SC && BL && !RESID;             // the ring holds hb instead of b (the residual wants b itself)
     static_assert(K <= 9, "stages are instantiated up to 9 sweeps");
     static_assert(PS == 0 || (PROLONG && ZERO && PS < K), "a prolongation inside the pipeline goes with a start from zero");
     static_assert(!(PROLONG && ZERO) || PS > 0, "x = 0 + P(c) before the first sweep is not a mode of the cycle");
@@ -296,6 +305,10 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                                 add0 = C0[SA][g];
                                 add1 = (C0[SA][g] + C1[SA][g]) / 2;
                             }
+                            if constexpr (SC && PS > 0) { // the stage-PS values are held times 4^PS
+                                constexpr double CP = (double)(1LL << (2 * PS));
+                                add0 *= CP, add1 *= CP;
+                            }
                             if (PL || ic[g][0]) v[g][0] += add0;
                             if (PL || ic[g][1]) v[g][1] += add1;
                         }
@@ -305,8 +318,10 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                 // ---- push b (row i-1)
                 if constexpr (BL) {
 #pragma unroll
-                    for (int g = 0; g < U; ++g)
+                    for (int g = 0; g < U; ++g) {
+                        if constexpr (HB) bcur[g][0] = h2 * bcur[g][0], bcur[g][1] = h2 * bcur[g][1];
                         *reinterpret_cast<double2 *>(G[0] + R * W + g * 128) = make_double2(bcur[g][0], bcur[g][1]);
+                    }
                 } else {
 #pragma unroll
                     for (int g = 0; g < U; ++g)
@@ -366,11 +381,24 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                             east = isR ? t : east;
                         }
                         const double c0v = w[s - 1][Q1][g][0], c1v = w[s - 1][Q1][g][1];
-                        double j0v = 0.25 * (c1v + west + w[s - 1][Q2][g][0] + w[s - 1][Q0][g][0] - h2 * bs[g][0]);
-                        double j1v = 0.25 * (east + c0v + w[s - 1][Q2][g][1] + w[s - 1][Q0][g][1] - h2 * bs[g][1]);
-                        if constexpr (DAMPED) j0v = c0v + om * (j0v - c0v), j1v = c1v + om * (j1v - c1v);
-                        o[g][0] = (PL || (rint && ic[g][0])) ? j0v : c0v;
-                        o[g][1] = (PL || (rint && ic[g][1])) ? j1v : c1v;
+                        if constexpr (SC) {
+                            constexpr double CS = (double)(1LL << (2 * (s - 1))); // scale of the window this stage reads
+                            const double hb0 = HB ? bs[g][0] : h2 * bs[g][0], hb1 = HB ? bs[g][1] : h2 * bs[g][1];
+                            const double j0v = __builtin_fma(-CS, hb0, c1v + west + w[s - 1][Q2][g][0] + w[s - 1][Q0][g][0]);
+                            const double j1v = __builtin_fma(-CS, hb1, east + c0v + w[s - 1][Q2][g][1] + w[s - 1][Q0][g][1]);
+                            o[g][0] = (PL || (rint && ic[g][0])) ? j0v : 4.0 * c0v;
+                            o[g][1] = (PL || (rint && ic[g][1])) ? j1v : 4.0 * c1v;
+                            if constexpr (s == K) {
+                                constexpr double INV = 1.0 / (double)(1LL << (2 * K));
+                                o[g][0] *= INV, o[g][1] *= INV;
+                            }
+                        } else {
+                            double j0v = 0.25 * (c1v + west + w[s - 1][Q2][g][0] + w[s - 1][Q0][g][0] - h2 * bs[g][0]);
+                            double j1v = 0.25 * (east + c0v + w[s - 1][Q2][g][1] + w[s - 1][Q0][g][1] - h2 * bs[g][1]);
+                            j0v = c0v + om * (j0v - c0v), j1v = c1v + om * (j1v - c1v);
+                            o[g][0] = (PL || (rint && ic[g][0])) ? j0v : c0v;
+                            o[g][1] = (PL || (rint && ic[g][1])) ? j1v : c1v;
+                        }
                     }
                     if constexpr (PROLONG && PS > 0 && s == PS) prolong_into(o);
                     if (s == K && a.xout && row >= rb && row < re) {
