@@ -138,7 +138,8 @@ int mg_prolong_add(const double *crs, int64_t cny, int64_t cnx, int64_t cld, dou
  * outside rows j0..j1-1 are not written.  Bit-identical to the same sequence of mg_prolong_add,
  * mg_jacobi and mg_residual calls (smooth_parallel, core/parallel_multigrid.py:100-114, with the
  * preceding interpolate_add_to, :309/:322), but x and b are read once and x written once.
- * Needs 16-byte aligned arrays with an even ld.
+ * Needs 16-byte aligned arrays with an even ld.  (Bit-identical while no intermediate leaves the normal
+ * range of a double: the pass keeps stage s's values times 4^s, exact scaling, and unscales at the end.)
   * Batches: nbatch grids, bstride elements apart in b/x_in/x_out/r (even), cstride in crs (and cbstride in
  * coarse_b below); one set of norm slots accumulates the max over all grids.
   * prolong_after = 0: the prolongation comes before the first sweep (x_in required).  prolong_after = 3

@@ -496,6 +496,38 @@ def test_fused_pass_partial_rows(L):
     assert np.all(got == 5.0)
 
 
+@pytest.mark.parametrize("mag", [2.0 ** -900, 2.0 ** -40, 2.0 ** 700, 2.0 ** 960])
+@pytest.mark.parametrize("sweeps,resid", [(6, False), (6, True), (3, True)])
+def test_fused_pass_is_exact_over_the_exponent_range(L, mag, sweeps, resid):
+    """The fused pass keeps stage s's values times 4^s (one fma per point instead of multiply, subtract,
+    multiply).  That is the reference's arithmetic bit for bit as long as no intermediate leaves the normal
+    range: data 2^-900 .. 2^960 times a standard normal sample, where the sequence of single sweeps is the
+    check (the mesh width is chosen so that h*h*b stays normal too)."""
+    import torch
+    rng = np.random.default_rng(123)
+    ny, nx = 150, 300
+    x, b = rng.standard_normal((ny, nx)) * mag, rng.standard_normal((ny, nx)) * mag
+    h = 0.75
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    db, dx = padded(b), padded(x)
+    ld = dx.stride(0)
+    cur, oth = padded(x), padded(x)
+    for _ in range(sweeps):
+        L.check(lib.mg_jacobi(db.data_ptr(), cur.data_ptr(), oth.data_ptr(), ny, nx, ld, 1, ny - 1, h, 1.0, 1, 0, 0, st))
+        cur, oth = oth, cur
+    r_ref = padded(np.zeros((ny, nx)))
+    L.check(lib.mg_residual(r_ref.data_ptr(), cur.data_ptr(), db.data_ptr(), ny, nx, ld, 1, ny - 1, h, None, 1, 0, 0, st))
+    out, rr = padded(x), padded(np.zeros((ny, nx)))
+    L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), out.data_ptr(), rr.data_ptr() if resid else None, None, ny, nx, ld,
+                                0, 0, 0, 1, ny - 1, 0, ny - 1, 0, sweeps, 0, h, 1.0, None, 1, 0, 0, st))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got).max() > 0
+    assert np.array_equal(got, cur.cpu().numpy())
+    if resid:
+        assert np.array_equal(rr.cpu().numpy(), r_ref.cpu().numpy())
+
+
 @pytest.mark.parametrize("shape", [(40, 121), (70, 249), (300, 257), (130, 1001), (600, 2051)], ids=str)
 @pytest.mark.parametrize("sweeps", [1, 3, 6])
 @pytest.mark.parametrize("mode", ["plain", "zero", "prolong"])
