@@ -1,0 +1,4 @@
+// Explicit instantiations of the fused pass (one slice of them per unit: they compile in parallel).
+#include "mg_fused_kernel.h"
+
+template int pick_mode<6, true>(const FusedArgs &, bool, bool, bool, bool, hipStream_t);
