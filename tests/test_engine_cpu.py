@@ -182,7 +182,8 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, di
 @pytest.mark.parametrize("dist_min_rows", [8, 16, None])
 @pytest.mark.parametrize("world,gny,gnx,n_para,fused", [(2, 65, 65, 2, True), (2, 65, 33, 1, True), (2, 129, 65, 3, True), (2, 129, 65, 3, False),
                                                         (4, 129, 129, 3, True), (4, 257, 33, 2, True),
-                                                        (4, 257, 33, 2, False)], ids=str)
+                                                        (4, 257, 33, 2, False),
+                                                        (8, 1025, 65, 4, True)], ids=str)
 def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused, dist_min_rows):
     b = _rhs(gny, gnx, 7)
     h = 0.37
