@@ -411,14 +411,17 @@ class SlabMultigrid:
         if self.fix_coarse_ascent:  # then the lower levels do feed xw[0]
             self._tail_below()
 
-    def _dead_levels(self):
+    def _has_dead_levels(self):
+        return self.eager_dead_levels and not self.fix_coarse_ascent and len(self.plan.whole) >= 2
+
+    def _dead_levels(self, after=None):
         """With the reference's loop bounds nothing in the cycle reads what the whole-domain levels
         below the first produce.  When they are computed every cycle they run beside the rest of
         the cycle, on the side stream; the cycle joins it at its end."""
-        if not self.eager_dead_levels or self.fix_coarse_ascent or len(self.plan.whole) < 2:
+        if not self._has_dead_levels():
             return
         o = self.ops
-        with o.side():
+        with o.side(after):
             if self.use_graph and self.world > 1:  # on one rank they are part of the cycle graph
                 if self._dead_graph is None:
                     o.graph_begin()
@@ -476,7 +479,13 @@ class SlabMultigrid:
                 self._mid_result = self._middle()
                 self._mid_graph = self.ops.graph_end()
             self.ops.graph_launch(self._mid_graph)
-        self._dead_levels()
+        # On one rank the side work is enqueued after the rest of the cycle (see _cycle), from this point of
+        # the main sequence: captured in that order the graph runs the ascent first and the dead levels beside
+        # it; captured right here, the ascent waited for most of them (0.26 ms per cycle at 32769 x 32769).
+        if self.world == 1:
+            self._dead_mark = self.ops.mark() if self._has_dead_levels() else None
+        else:
+            self._dead_levels()
         return self._mid_result
 
     def _cycle(self, store_r=False):
@@ -499,6 +508,8 @@ class SlabMultigrid:
         if k == 1:
             corr = self._window(corr, 1)
         self._smooth_level0(self.N2, want_norm=True, crs=corr, store_r=store_r)
+        if self.world == 1 and self._dead_mark is not None:
+            self._dead_levels(after=self._dead_mark)
         self.ops.join_side()
 
     # ------------------------------------------------------------------ drivers

@@ -41,12 +41,19 @@ class HipOps:
     # join_side() makes the main stream wait for it.  Both are event record/wait pairs, so they
     # also work while the main stream is being captured into a graph (the side stream joins the capture
     # and must be joined back before the capture ends).
-    @contextlib.contextmanager
-    def side(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(self.device)
+    def mark(self):
+        """A point of the main sequence that side(after=...) can start from later."""
         ev = torch.cuda.Event()
         ev.record(self.stream)
+        return ev
+
+    @contextlib.contextmanager
+    def side(self, after=None):
+        """after: a mark() -- the side work starts once the main sequence has reached that point,
+        though it is enqueued (or captured) later; default: everything enqueued so far."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        ev = after if after is not None else self.mark()
         self._side.wait_event(ev)
         self._on_side, self._side_pending = True, True
         try:

@@ -49,7 +49,10 @@ class OracleOps:
     def synchronize(self):
         pass
 
-    def side(self):
+    def mark(self):
+        return None
+
+    def side(self, after=None):
         return contextlib.nullcontext()
 
     def join_side(self):
