@@ -131,7 +131,10 @@ class SlabMultigrid:
         # the last distributed level restricts into a slab, which is all-gathered into b[n_dist]
         self._bslab = z(P.levels[n_dist].ny, P.levels[n_dist].ld) if world > 1 else None
         self._cur0 = 0  # which of (_xa[0], _xb[0]) holds the finest x
-        self.norm = ops.norm_slots()
+        # two accumulators, used in turn (the one the finest x's parity selects): the host can read a cycle's
+        # norm while the next cycle, which resets and fills the other one, is already running
+        self._norms = [ops.norm_slots(), ops.norm_slots()]
+        self.norm = self._norms[0]
         # Whole-domain levels, on every rank.  The first one shares the rows of the (replicated)
         # staging level: local row t of the padded arrays is global row t - H.
         self.xw, self.bw, self.rw = [], [], []
@@ -397,7 +400,7 @@ class SlabMultigrid:
             self._b0_halo_valid = True
         # the residual of the finest level is restricted right away: b_1 is ready for the next descent
         store_r = store_r or self.store_residual_every_cycle or not self.fused
-        res = self._smooth(0, xs[self._cur0], crs, n, self.r[0] if store_r else None, self.norm if want_norm else None,
+        res = self._smooth(0, xs[self._cur0], crs, n, self.r[0] if store_r else None, self._norms[self._cur0] if want_norm else None,
                            finest=True, crs_has_halo=self.n_dist == 1, restrict=True)
         self._r0_stale = not store_r
         self._cur0 = 0 if res is xs[0] else 1
@@ -514,6 +517,7 @@ class SlabMultigrid:
 
     # ------------------------------------------------------------------ drivers
     def _run_cycle(self, store_r=False):
+        self._last_parity = self._cur0  # selects the norm accumulator this cycle fills
         store_r = bool(store_r) and self.fused and not self.store_residual_every_cycle
         if self.use_graph and self.world == 1:
             # one graph per array the finest x starts the cycle in (a cycle may leave it in the other)
@@ -543,21 +547,38 @@ class SlabMultigrid:
                 self._graphs[(start, store_r)] = (self.ops.graph_end(), self._cur0)
         self._cur0, self._r0_stale = cur, stale
 
-    def _global_err(self):
+    def _global_err(self, parity=None, mark=None):
         """max|r| over all ranks.  The accumulator holds bit patterns of |r| as integers, an order that
         agrees with the order of the values and puts NaN above everything: one integer MAX-reduction
         of the slots gives every rank the global accumulator, NaN included."""
+        norm = self._norms[self._last_parity if parity is None else parity]
         if self.world > 1:
-            self.comm.allreduce_max(self.norm)
-        return self.ops.norm_read(self.norm)
+            self.comm.allreduce_max(norm)
+        if mark is not None:
+            return self.ops.norm_read_at(norm, mark)
+        return self.ops.norm_read(norm)
 
     def cycles(self, k):
         """Run exactly k V-cycles (no stop test); returns max|r| after each."""
         errs = []
         self.ops.begin()
+        pending = None
         for c in range(k):
             self._run_cycle(store_r=c == k - 1)  # the last pass leaves the residual array current
-            errs.append(self._global_err())
+            if self.world > 1:
+                errs.append(self._global_err())
+                continue
+            # one rank: every cycle's norm is read, but after the next cycle has been enqueued, so the
+            # GPU does not idle while the host waits for the number and launches the next graph
+            here = (self._last_parity, self.ops.mark())
+            if pending is not None:
+                errs.append(self._global_err(*pending))
+            pending = here
+            if self._cur0 == self._last_parity:  # the next cycle fills the same accumulator: read now
+                errs.append(self._global_err(*pending))
+                pending = None
+        if pending is not None:
+            errs.append(self._global_err(*pending))
         self.ops.end()
         self.materialize_residual()
         return errs

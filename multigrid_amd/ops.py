@@ -24,6 +24,7 @@ class HipOps:
         # a stream of its own: the null stream cannot be captured into a hipGraph
         self.stream = torch.cuda.Stream(self.device)
         self._side, self._on_side, self._side_pending = None, False, False
+        self._copy = None
 
     # ---- memory / stream plumbing (torch) -------------------------------------------------
     def zeros(self, rows, ld, batch=None):
@@ -177,6 +178,16 @@ class HipOps:
         """max of the accumulator; waits for the stream."""
         out = C.c_double()
         check(self.L.mg_norm_read(slots.data_ptr(), C.byref(out), self._s))
+        return out.value
+
+    def norm_read_at(self, slots, mark):
+        """max of the accumulator as it stands at a mark() of the main sequence: read on a stream of its
+        own, so work enqueued after the mark keeps running while the host waits."""
+        if self._copy is None:
+            self._copy = torch.cuda.Stream(self.device)
+        self._copy.wait_event(mark)
+        out = C.c_double()
+        check(self.L.mg_norm_read(slots.data_ptr(), C.byref(out), self._copy.cuda_stream))
         return out.value
 
     # ---- hipGraph ----------------------------------------------------------------------------

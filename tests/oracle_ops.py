@@ -170,3 +170,6 @@ class OracleOps:
 
     def norm_read(self, slots):
         return float(slots.view(torch.float64)[0].item())
+
+    def norm_read_at(self, slots, mark):
+        return self.norm_read(slots)
