@@ -169,10 +169,10 @@ int cycle(mg_solver *s, bool store_r)
     if (s->fix_coarse_ascent) {
         if (tail_below(s, st)) return 1;
     } else if (s->eager_dead && s->wl.size() > 1) {
-        // nothing in the cycle reads these levels: beside the ascent, on the second stream
+        // nothing in the cycle reads these levels: they run beside the ascent, on the second stream, from
+        // this point of the main sequence on -- but are enqueued after it (below): captured in that order the
+        // graph starts the ascent at once; captured here, the ascent waited for most of them
         MG_HIP(hipEventRecord(s->fork, st));
-        MG_HIP(hipStreamWaitEvent(s->side, s->fork, 0));
-        if (tail_below(s, s->side)) return 1;
         forked = true;
     }
     // ascent (:306-313): prolongation + N2 sweeps; the residuals of these levels are never read
@@ -195,6 +195,8 @@ int cycle(mg_solver *s, bool store_r)
     }
     if (finest_pass(s, N2, crs, cny, cnx, cld, true, store_r)) return 1;
     if (forked) {
+        MG_HIP(hipStreamWaitEvent(s->side, s->fork, 0));
+        if (tail_below(s, s->side)) return 1;
         MG_HIP(hipEventRecord(s->join, s->side));
         MG_HIP(hipStreamWaitEvent(st, s->join, 0));
     }
