@@ -44,6 +44,8 @@ const char *mg_last_error(void);
  *   "rows"        0..4096    rows per workgroup tile, 0 = automatic
  *   "linear_map"  0 | 1      1 disables the XCD-aware workgroup -> tile mapping
  *   "fused_waves" 1 | 2 | 4  column strips (waves) per workgroup of the fused passes
+ *   "fused_min_rows" 4..128  shortest tile (rows) the fused passes choose on levels too small to fill the chip
+ *   "fused_min_blocks" n     ... tiles are halved while a launch has fewer workgroups than this
  *   "sor_single_wave" 0|1|2  mg_sor, lexicographic: barrier-free one-wave kernel never / where it is
  *                            faster (default) / wherever the grid fits */
 int mg_set_tuning(const char *key, int value);

@@ -30,6 +30,8 @@
 int g_fused_waves = 4; // waves (column strips) per workgroup: tuning knob "fused_waves"
 int g_fused_unroll = 2;
 int g_fused_rows = 0;
+int g_fused_min_rows = 8;
+int g_fused_min_blocks = 2048;
 
 extern "C" int mg_set_fused_tuning(int unroll, int rows)
 {

@@ -548,6 +548,8 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
 extern int g_fused_waves;  // waves (column strips) per workgroup: tuning knob "fused_waves"
 extern int g_fused_unroll; // column pairs per lane of the shallow passes
 extern int g_fused_rows;   // rows per tile, 0 = automatic
+extern int g_fused_min_rows; // shortest tile the automatic choice goes down to on small levels
+extern int g_fused_min_blocks; // ... as long as the launch has fewer workgroups than this
 
 template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0, bool DAMPED = false>
 int launch_fused(FusedArgs a, hipStream_t st)
@@ -565,7 +567,9 @@ int launch_fused(FusedArgs a, hipStream_t st)
         // measured at 32769 x 32769 (profiles/): 64-row tiles are as fast as or faster than taller ones at
         // every depth, 32-row tiles faster still for the shallow from-zero pass
         rpb = D <= 5 ? 32 : (D >= 9 ? 128 : 64); // the 9-sweep pass streams 9 extra rows per tile end: taller tiles
-        while (rpb > 8 * D && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) * a.nbatch < 2048) rpb >>= 1;
+        // a small level cannot fill the chip, and its pass lasts as long as one wave needs for one tile:
+        // shorter tiles (down to g_fused_min_rows) cut that time; the extra overlap rows cost nothing there
+        while (rpb > g_fused_min_rows && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) * a.nbatch < g_fused_min_blocks) rpb >>= 1;
     }
     a.rpb = rpb;
     a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);

@@ -221,11 +221,13 @@ __global__ __launch_bounds__(256) void mg_maxabs_kernel(const double *__restrict
 
 // ---- tuning knobs (speed only; results never depend on them) -------------------------------
 static int g_vec_cap = 2;   // doubles per access: 1 or 2
-static int g_unroll = 2;    // accesses per lane and row: 1, 2 or 4
+static int g_unroll = 1;    // accesses per lane and row: 1, 2 or 4
 static int g_rows = 0;      // rows per tile, 0 = automatic
 static int g_linear_map = 0;
 extern int g_sor_single_wave; // mg_sor.hip
 extern int g_fused_waves;     // mg_fused.hip
+extern int g_fused_min_rows;  // mg_fused.hip
+extern int g_fused_min_blocks; // mg_fused.hip
 
 extern "C" int mg_set_tuning(const char *key, int value)
 {
@@ -244,6 +246,12 @@ extern "C" int mg_set_tuning(const char *key, int value)
     } else if (!strcmp(key, "fused_waves")) {
         MG_REQUIRE(value == 1 || value == 2 || value == 4, "mg_set_tuning: fused_waves must be 1, 2 or 4");
         g_fused_waves = value;
+    } else if (!strcmp(key, "fused_min_rows")) {
+        MG_REQUIRE(value >= 4 && value <= 128, "mg_set_tuning: fused_min_rows must be 4..128");
+        g_fused_min_rows = value;
+    } else if (!strcmp(key, "fused_min_blocks")) {
+        MG_REQUIRE(value >= 1 && value <= (1 << 20), "mg_set_tuning: fused_min_blocks must be 1..2^20");
+        g_fused_min_blocks = value;
     } else if (!strcmp(key, "sor_single_wave")) {
         MG_REQUIRE(value >= 0 && value <= 2, "mg_set_tuning: sor_single_wave must be 0, 1 or 2");
         g_sor_single_wave = value;
@@ -257,9 +265,12 @@ extern "C" int mg_set_tuning(const char *key, int value)
 static int rows_per_block(i64 nrows, int ncb, i64 nbatch)
 {
     if (g_rows > 0) return g_rows;
-    // Tall tiles amortise the two halo rows (2/rpb extra reads); small grids need short tiles to
-    // produce enough workgroups for 256 CUs.
-    int rpb = 128;
+    // Short tiles: workgroups are dispatched in address order and live for a few rows, so what the chip
+    // touches at any moment is one dense band of the arrays, which HBM serves faster than many rows far
+    // apart (measured at 32769 x 32769: 4 rows 4.78 ms per sweep, 128 rows 5.08 ms, 1 row 5.65 ms; a plain
+    // a + b kernel: one access per thread and no loop 6.0 TB/s, grid-stride loop 4.9-5.5, tools/copy_probe).
+    // The two halo rows a tile re-reads come from L2 / the Infinity Cache.
+    int rpb = 4;
     while (rpb > 4 && (i64)ncb * ((nrows + rpb - 1) / rpb) * nbatch < 4096) rpb >>= 1;
     return rpb;
 }

@@ -7,6 +7,8 @@ The engine only ever talks to an object with this interface.
 import contextlib
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -27,7 +29,29 @@ class HipOps:
         self._copy = None
 
     # ---- memory / stream plumbing (torch) -------------------------------------------------
+    alloc_skew = int(os.environ.get("MG_ALLOC_SKEW", "0"))  # experiment: bytes of offset between successive arrays
+
     def zeros(self, rows, ld, batch=None):
+        pool_gb = int(os.environ.get("MG_POOL_GB", "0"))  # experiment: all arrays from one allocation
+        if pool_gb:
+            if getattr(self, "_pool", None) is None:
+                self._pool = torch.zeros(pool_gb << 27, dtype=torch.float64, device=self.device)
+                self._pool_off = 0
+            n = rows * ld * (batch or 1)
+            al = int(os.environ.get("MG_POOL_ALIGN", "2097152")) // 8
+            off = (self._pool_off + al - 1) // al * al
+            self._pool_off = off + n
+            v = self._pool[off : off + n]
+            return v.view((rows, ld) if batch is None else (batch, rows, ld))
+        if self.alloc_skew and batch is None and rows * ld * 8 >= (1 << 26):
+            # large arrays start at staggered offsets inside their allocations, so that the row streams of
+            # one pass (x, b, x_out at the same row) do not line up on the same memory channels
+            self._nalloc = getattr(self, "_nalloc", 0) + 1
+            pad = 1 << 18
+            off = (self._nalloc * self.alloc_skew // 8) % pad
+            off -= off % 16
+            flat = torch.zeros(rows * ld + pad, dtype=torch.float64, device=self.device)
+            return flat[off : off + rows * ld].view(rows, ld)
         return torch.zeros((rows, ld) if batch is None else (batch, rows, ld), dtype=torch.float64, device=self.device)
 
     def norm_slots(self):

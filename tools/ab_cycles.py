@@ -19,6 +19,7 @@ def main():
     import bench
     from multigrid_amd.engine import SlabMultigrid
     n = args.exp
+    dummy = [torch.zeros(int(os.environ.get("MG_DUMMY_GB", "0")) << 27, dtype=torch.float64, device="cuda")]  # experiment: where the arrays land
     N = 2 ** (n + 1) + 1
     eng = SlabMultigrid(N, N, 8, 20.0 / 2 ** (n + 1), 0.025, eager_dead_levels=True)
     bench.fill_rhs(eng, torch, n, 0)

@@ -28,6 +28,26 @@ __global__ __launch_bounds__(256) void add_gs(const double2* __restrict__ a, con
     double2 x = a[i], y = b[i]; o[i] = make_double2(x.x + y.x, x.y + y.y);
   }
 }
+// no loop: one workgroup per 256, 512 (two adjacent 16-B accesses per thread) or 1024 (four accesses, 4 KB apart) pairs
+__global__ __launch_bounds__(256) void add_flat1(const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ o, i64 n2) {
+  i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n2) { double2 x = a[i], y = b[i]; o[i] = make_double2(x.x + y.x, x.y + y.y); }
+}
+__global__ __launch_bounds__(256) void add_flat2(const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ o, i64 n2) {
+  i64 i = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i + 1 < n2) {
+    double2 x0 = a[i], x1 = a[i + 1], y0 = b[i], y1 = b[i + 1];
+    o[i] = make_double2(x0.x + y0.x, x0.y + y0.y); o[i + 1] = make_double2(x1.x + y1.x, x1.y + y1.y);
+  }
+}
+__global__ __launch_bounds__(256) void add_flat4(const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ o, i64 n2) {
+  i64 i = (i64)blockIdx.x * 1024 + threadIdx.x;
+  if (i + 768 < n2) {
+    double2 x0 = a[i], x1 = a[i + 256], x2 = a[i + 512], x3 = a[i + 768], y0 = b[i], y1 = b[i + 256], y2 = b[i + 512], y3 = b[i + 768];
+    o[i] = make_double2(x0.x + y0.x, x0.y + y0.y); o[i + 256] = make_double2(x1.x + y1.x, x1.y + y1.y);
+    o[i + 512] = make_double2(x2.x + y2.x, x2.y + y2.y); o[i + 768] = make_double2(x3.x + y3.x, x3.y + y3.y);
+  }
+}
 // read-only: what the read side alone can stream (one double per block is written)
 __global__ __launch_bounds__(256) void read_gs(const double2* __restrict__ a, double* __restrict__ o, i64 n2) {
   double acc = 0;
@@ -74,6 +94,13 @@ int main(int argc, char** argv) {
   }
   report("memcpyDtoD", 2.0 * n * 8, [&] { CK(hipMemcpyAsync(o, a, n * 8, hipMemcpyDeviceToDevice, 0)); });
   for (int blocks : {2048, 8192})  {
+    char nm[64]; snprintf(nm, 64, "add_gs (2R1W) blocks=%d", blocks);
+    report(nm, 3.0 * n * 8, [&] { hipLaunchKernelGGL(add_gs, dim3(blocks), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (double2*)o, n2); });
+  }
+  report("add_flat1 (2R1W, no loop)", 3.0 * n * 8, [&] { hipLaunchKernelGGL(add_flat1, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (double2*)o, n2); });
+  report("add_flat2 (2R1W, no loop)", 3.0 * n * 8, [&] { hipLaunchKernelGGL(add_flat2, dim3((unsigned)((n2 / 2 + 255) / 256)), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (double2*)o, n2); });
+  report("add_flat4 (2R1W, no loop)", 3.0 * n * 8, [&] { hipLaunchKernelGGL(add_flat4, dim3((unsigned)(n2 / 1024)), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (double2*)o, n2); });
+  for (int blocks : {65536, 262144}) {
     char nm[64]; snprintf(nm, 64, "add_gs (2R1W) blocks=%d", blocks);
     report(nm, 3.0 * n * 8, [&] { hipLaunchKernelGGL(add_gs, dim3(blocks), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (double2*)o, n2); });
   }

@@ -29,9 +29,9 @@ def per_kernel(path, counter):
 # bytes per updated finest-level point: (per-operation compulsory bytes x the operations of the launch,
 # what the launch itself must move)
 BYTES = {
-    "void mg_stencil5_kernel<0, 2, 2, true>": (24, 24),
-    "void mg_stencil5_kernel<3, 2, 2, true>": (24, 24),
-    "void mg_stencil5_kernel<1, 2, 2, true>": (16, 16),
+    "void mg_stencil5_kernel<0, 2, 1, true>": (24, 24),
+    "void mg_stencil5_kernel<3, 2, 1, true>": (24, 24),
+    "void mg_stencil5_kernel<1, 2, 1, true>": (16, 16),
     "void mg_restrict_kernel<true>": (10, 10),
     "void mg_prolong_kernel<true, true>": (18, 18),
     "void mg_fused_kernel<6, true, false, true, false, 1, 0, false>": (18 + 6 * 24 + 24, 8 + 2 + 8 + 8 + 8),
@@ -66,7 +66,7 @@ def main():
         return kernels[name]["hbm_bytes"] if name in kernels else None
 
     out = {
-        "jacobi_finest_bytes_per_launch": total("void mg_stencil5_kernel<0, 2, 2, true>"),
+        "jacobi_finest_bytes_per_launch": total("void mg_stencil5_kernel<0, 2, 1, true>"),
         "fused_finest_bytes_per_launch": total("void mg_fused_kernel<6, true, false, true, true, 1, 0, false>"),
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/pmc_probe.py, "
                 f"{2 ** (args.n + 1) + 1} squared; FETCH_SIZE (KiB) doubled per the gfx950 correction for 16-B/lane "
