@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-fused", action="store_true", help="one kernel per operation instead of fused passes")
     ap.add_argument("--no-recompute", action="store_true",
                     help="coarse levels store x after the pre-smoothing instead of recomputing it in the post-smoothing pass")
+    ap.add_argument("--no-tune-placement", action="store_true",
+                    help="allocate the level arrays where the allocator puts them instead of timing a few "
+                         "placements of the finest level's arrays at set-up and keeping the fastest")
     ap.add_argument("--batch", type=int, default=0,
                     help="B > 0: B independent (2**(n+1)+1)^2 problems advance together on one GPU "
                          "(e.g. --batch 1024 --exp 7 --jacobi-levels 4); not the headline workload")
@@ -177,7 +180,8 @@ def main():
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
                         use_graph=not args.no_graph, fused=not args.no_fused,
                         eager_dead_levels=not args.lazy_dead_levels, batch=args.batch or None,
-                        recompute_presmoothing=not args.no_recompute, jacobi_omega=args.jacobi_omega)
+                        recompute_presmoothing=not args.no_recompute, jacobi_omega=args.jacobi_omega,
+                        tune_placement=not args.no_tune_placement)
     nprob = args.batch or 1
     fill_rhs(eng, torch, n, rank)
     torch.cuda.synchronize()
@@ -272,6 +276,7 @@ def main():
                 "n": n, "n_para": n_para, "grid": [gny, gnx], "batch": args.batch or None, "unknowns": unknowns,
                 "coarse_ordering": args.ordering, "jacobi_omega": args.jacobi_omega, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
                 "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph), "fused_passes": bool(eng.fused), "recompute_presmoothing": bool(eng.recompute_presmoothing and eng.fused),
+                "placement_spacer_gib": eng.placement_gib,
                 "halo_rows": eng.plan.halo, "distributed_levels": eng.n_dist if world > 1 else None,
                 "dead_whole_domain_levels": "computed every cycle" if eng.eager_dead_levels else "on demand", "backend": args.backend if world > 1 else None,
             },

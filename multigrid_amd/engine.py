@@ -47,7 +47,8 @@ class SlabMultigrid:
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
                  store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
-                 recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0):
+                 recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=False,
+                 overlap_min_rows=4096):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -124,10 +125,18 @@ class SlabMultigrid:
         z = (lambda rows, ld: ops.zeros(rows, ld, batch)) if batch is not None else ops.zeros
         # Jacobi levels: two x arrays (ping-pong), b, r.  b has one more level (the staging level).
         LV = self.lv
-        self._xa = [z(L.ny, L.ld) for L in LV[:n_para]]
-        self._xb = [z(L.ny, L.ld) for L in LV[:n_para]]
-        self.b = [z(L.ny, L.ld) for L in LV]
-        self.r = [z(L.ny, L.ld) for L in LV[:n_para]]
+        # tune_placement: try where in HBM the finest level's arrays stream fastest (HipOps.placement_spacer)
+        spacer = None
+        self.placement_gib = None  # GiB skipped in front of the level arrays (None: placement not tuned)
+        if tune_placement and batch is None and hasattr(ops, "placement_spacer"):
+            spacer = ops.placement_spacer(LV[0].ny, LV[0].ld, verbose=tune_placement == "verbose")
+            self.placement_gib = 0 if spacer is None else spacer.numel() >> 27
+        # the finest level's arrays first, in this order (the placement search allocates the same way)
+        fin = [z(LV[0].ny, LV[0].ld) for _ in range(4)]
+        self._xa = [fin[0]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
+        self._xb = [fin[1]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
+        self.b = [fin[2]] + [z(L.ny, L.ld) for L in LV[1:]]
+        self.r = [fin[3]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
         # the last distributed level restricts into a slab, which is all-gathered into b[n_dist]
         self._bslab = z(P.levels[n_dist].ny, P.levels[n_dist].ld) if world > 1 else None
         self._cur0 = 0  # which of (_xa[0], _xb[0]) holds the finest x
@@ -148,6 +157,17 @@ class SlabMultigrid:
             self.xw.append(z(W.ny, W.ld))
             self.bw.append(z(W.ny, W.ld))
             self.rw.append(z(W.ny, W.ld))
+        if spacer is not None:  # the arrays stay where they are
+            del spacer
+            torch.cuda.empty_cache()
+        # Several ranks, fused passes: a pass that follows a halo exchange is cut into the rows that depend
+        # on owned rows only -- launched at once, beside the exchange, which runs on a stream of its own --
+        # and the few rows at both slab ends, launched once the halo rows have arrived.  Done on levels
+        # with at least overlap_min_rows rows per rank (None: never); on smaller ones the two extra launches
+        # cost more than the exchange they hide.
+        self.overlap_min_rows = overlap_min_rows if (world > 1 and self.fused and hasattr(ops, "comm_side")) else None
+        self.split_passes = 0  # passes cut this way so far (diagnostics)
+        self._pending = None  # (level, exchange items) of a right-hand side whose halo is still to be filled
         self._graphs = {}
         self._xchg_cache = {}
         self._mid_graph = None
@@ -258,6 +278,61 @@ class SlabMultigrid:
         self._xchg_cache[key] = self.comm.prepare(sends, recvs)
         self.comm.run(self._xchg_cache[key])
 
+    def _overlaps(self, l, D):
+        """Is a pass of depth D on level l cut into interior and slab ends around its exchange?"""
+        if self.overlap_min_rows is None or self.world == 1 or l >= self.n_dist:
+            return False
+        R = self.plan.levels[l].rows
+        return R >= self.overlap_min_rows and R >= 4 * (D + 4)
+
+    def _defer_exchange(self, l, items):
+        """The halo of level l's right-hand side, just produced, is needed by the level's descent pass, which
+        comes next: leave the exchange to that pass, which hides it behind its interior rows."""
+        self._flush_pending()
+        self._pending = (l, items)
+
+    def _take_pending(self, l):
+        """The deferred exchange for level l's descent pass ([] if there is none); one that was meant for
+        another consumer is carried out now."""
+        if self._pending is not None and self._pending[0] == l:
+            items, self._pending = self._pending[1], None
+            return items
+        self._flush_pending()
+        return []
+
+    def _flush_pending(self):
+        if self._pending is not None:
+            items, self._pending = self._pending[1], None
+            self._exchange(items)
+
+    def _pass(self, l, D, items, launch):
+        """One fused pass over level l that reads D rows beyond the rows it produces, after the halo exchange
+        `items`.  launch(j0, j1) enqueues the pass for local rows j0 <= j < j1."""
+        L = self.lv[l]
+        if not items or not self._overlaps(l, D):
+            if items:
+                self._exchange(items)
+            launch(L.t0, L.t1)
+            return
+        # Interior: rows whose inputs, D rows up and down and the coarse rows around those, are owned rows.
+        # The cuts are even rows (relative to the even halo depth): fine centres of coarse rows, so the
+        # coarse rows of a fused restriction split with them.
+        self.split_passes += 1
+        H, R = L.halo, L.rows
+        m = D + 2 + (D & 1)
+        a, e = H + m, H + R - m
+        with self.ops.comm_side():
+            self._exchange(items)
+        launch(a, e)
+        self.ops.comm_join()
+        launch(L.t0, a)
+        launch(e, L.t1)
+
+    @staticmethod
+    def _coarse_rows(Lc, H, j0, j1):
+        """Coarse rows whose fine centre row 2T - H is one of j0 .. j1-1, within the rows Lc updates."""
+        return max(Lc.t0, (j0 + H + 1) // 2), min(Lc.t1, (j1 + H + 1) // 2)
+
     # ------------------------------------------------------------------ building blocks
     @staticmethod
     def _chunks(n, most=6):
@@ -280,23 +355,42 @@ class SlabMultigrid:
         # where the restriction goes: the next level's b, or the slab that is then all-gathered into it
         Lc = self.plan.levels[l + 1] if to_rep else self.lv[l + 1]
         cb = self._bslab if to_rep else self.b[l + 1]
+        H = L.halo
+
+        def crows(j0, j1):  # the coarse rows a launch over fine rows j0 .. j1-1 restricts into
+            return (Lc.t0, Lc.t1) if (j0, j1) == (L.t0, L.t1) else self._coarse_rows(Lc, H, j0, j1)
+
+        def after_restriction():  # the next level's right-hand side has been produced
+            if to_rep:
+                self._allgather_b(l + 1)
+            elif dist_:
+                items = [(self.b[l + 1], Lc, self.plan.halo - 1)]
+                # its first reader is the next level's descent pass: let that pass hide the exchange
+                if l + 1 < self.n_dist and self._overlaps(l + 1, self.N1 + 2):
+                    self._defer_exchange(l + 1, items)
+                else:
+                    self._exchange(items)
+
+        pend = self._take_pending(l) if self.fused else []
         if self.fused and self._recomputed(l):
             if src is None:  # descent: only the restricted residual leaves the pass
                 assert restrict and crs is None
-                o.smooth_fused(self.b[l], None, None, r, None, L.nx, cnx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, n, L.h,
-                               norm, cb, Lc.nx, Lc.t0, Lc.t1, omega=self.jacobi_omega)
-                if to_rep:
-                    self._allgather_b(l + 1)
-                elif dist_:
-                    self._exchange([(self.b[l + 1], Lc, self.plan.halo - 1)])
+
+                def launch(j0, j1):
+                    o.smooth_fused(self.b[l], None, None, r, None, L.nx, cnx, j0, j1, L.fix_lo, L.fix_hi, L.oj, n, L.h,
+                                   norm, cb, Lc.nx, *crows(j0, j1), omega=self.jacobi_omega)
+                self._pass(l, n + 2, pend, launch)
+                after_restriction()
                 return None
             # ascent: N1 sweeps from zero, + P(crs), the n post-smoothing sweeps; of a slab's
             # neighbours only the correction's halo is needed (b's was exchanged when b was made)
-            assert crs is not None and not restrict
-            if dist_ and not crs_has_halo:
-                self._exchange([(crs, self.lv[l + 1], (self.N1 + n) // 2 + 2)])
-            o.smooth_fused(self.b[l], None, xa, r, crs, L.nx, cnx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, self.N1 + n, L.h,
-                           norm, prolong_after=self.N1, omega=self.jacobi_omega)
+            assert crs is not None and not restrict and not pend
+            items = [(crs, self.lv[l + 1], (self.N1 + n) // 2 + 2)] if (dist_ and not crs_has_halo) else []
+
+            def launch(j0, j1):
+                o.smooth_fused(self.b[l], None, xa, r, crs, L.nx, cnx, j0, j1, L.fix_lo, L.fix_hi, L.oj, self.N1 + n, L.h,
+                               norm, prolong_after=self.N1, omega=self.jacobi_omega)
+            self._pass(l, self.N1 + n + (1 if r is not None else 0), items, launch)
             return xa
         if self.fused:
             extra = (2 if restrict else 1 if r is not None else 0)
@@ -305,24 +399,25 @@ class SlabMultigrid:
                 dst = xa if (src is None or src is xb) else xb
                 first, last = ci == 0, ci == len(chunks) - 1
                 depth = k + (extra if last else 0)
+                items = pend if first else []
                 if src is not None and dist_:  # the pass reads `depth` rows beyond the rows it produces
-                    items = [(src, L, depth)]
+                    items = items + [(src, L, depth)]
                     if first and crs is not None and not crs_has_halo:
                         items.append((crs, self.lv[l + 1], depth // 2 + 2))
-                    self._exchange(items)
                 if last and norm is not None:
                     o.norm_reset(norm)
                 if last and restrict:
-                    o.smooth_fused(self.b[l], src, dst, r, crs if first else None, L.nx, cnx, L.t0, L.t1, L.fix_lo,
-                                   L.fix_hi, L.oj, k, L.h, norm, cb, Lc.nx, Lc.t0, Lc.t1, omega=self.jacobi_omega)
+                    def launch(j0, j1, src=src, dst=dst, first=first, k=k):
+                        o.smooth_fused(self.b[l], src, dst, r, crs if first else None, L.nx, cnx, j0, j1, L.fix_lo,
+                                       L.fix_hi, L.oj, k, L.h, norm, cb, Lc.nx, *crows(j0, j1), omega=self.jacobi_omega)
                 else:
-                    o.smooth_fused(self.b[l], src, dst, r if last else None, crs if first else None, L.nx, cnx, L.t0,
-                                   L.t1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None, omega=self.jacobi_omega)
+                    def launch(j0, j1, src=src, dst=dst, first=first, last=last, k=k):
+                        o.smooth_fused(self.b[l], src, dst, r if last else None, crs if first else None, L.nx, cnx, j0,
+                                       j1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None, omega=self.jacobi_omega)
+                self._pass(l, depth, items, launch)
                 src = dst
-            if restrict and to_rep:
-                self._allgather_b(l + 1)
-            elif restrict and dist_:
-                self._exchange([(self.b[l + 1], Lc, self.plan.halo - 1)])
+            if restrict:
+                after_restriction()
             return src
         # one kernel per operation, one single-row exchange per sweep
         if src is None:
@@ -547,16 +642,25 @@ class SlabMultigrid:
                 self._graphs[(start, store_r)] = (self.ops.graph_end(), self._cur0)
         self._cur0, self._r0_stale = cur, stale
 
-    def _global_err(self, parity=None, mark=None):
-        """max|r| over all ranks.  The accumulator holds bit patterns of |r| as integers, an order that
-        agrees with the order of the values and puts NaN above everything: one integer MAX-reduction
-        of the slots gives every rank the global accumulator, NaN included."""
-        norm = self._norms[self._last_parity if parity is None else parity]
+    def _reduce_err(self, parity=None):
+        """Enqueue the MAX-reduction of a norm accumulator over the ranks (nothing to do on one).  The
+        accumulator holds bit patterns of |r| as integers, an order that agrees with the order of the
+        values and puts NaN above everything: one integer MAX-reduction of the slots gives every rank
+        the global accumulator, NaN included."""
         if self.world > 1:
-            self.comm.allreduce_max(norm)
+            self.comm.allreduce_max(self._norms[self._last_parity if parity is None else parity])
+
+    def _read_err(self, parity=None, mark=None):
+        """max|r| from a (reduced) accumulator: as it stands at `mark` of the main sequence, or now."""
+        norm = self._norms[self._last_parity if parity is None else parity]
         if mark is not None:
             return self.ops.norm_read_at(norm, mark)
         return self.ops.norm_read(norm)
+
+    def _global_err(self, parity=None, mark=None):
+        """max|r| over all ranks."""
+        self._reduce_err(parity)
+        return self._read_err(parity, mark)
 
     def cycles(self, k):
         """Run exactly k V-cycles (no stop test); returns max|r| after each."""
@@ -565,20 +669,22 @@ class SlabMultigrid:
         pending = None
         for c in range(k):
             self._run_cycle(store_r=c == k - 1)  # the last pass leaves the residual array current
-            if self.world > 1:
-                errs.append(self._global_err())
-                continue
-            # one rank: every cycle's norm is read, but after the next cycle has been enqueued, so the
-            # GPU does not idle while the host waits for the number and launches the next graph
+            # Every cycle's norm is read, but after the next cycle has been enqueued, so the GPU does not
+            # idle while the host waits for the number and issues the next cycle (on one rank a graph
+            # launch; on several the launches and exchange rounds of the small distributed levels, which
+            # the host issues more slowly than the GPU runs them: behind the previous cycle's finest pass
+            # they cost nothing).  The reduction over the ranks is enqueued with its cycle.
+            self._reduce_err()
             here = (self._last_parity, self.ops.mark())
             if pending is not None:
-                errs.append(self._global_err(*pending))
+                errs.append(self._read_err(*pending))
             pending = here
             if self._cur0 == self._last_parity:  # the next cycle fills the same accumulator: read now
-                errs.append(self._global_err(*pending))
+                errs.append(self._read_err(*pending))
                 pending = None
         if pending is not None:
-            errs.append(self._global_err(*pending))
+            errs.append(self._read_err(*pending))
+        self._flush_pending()
         self.ops.end()
         self.materialize_residual()
         return errs
@@ -587,6 +693,7 @@ class SlabMultigrid:
         """The single Jacobi sweep + residual that opens solve() (parallel_multigrid.py:264-266)."""
         self.ops.begin()
         self._smooth_level0(1, want_norm=False)
+        self._flush_pending()
         self.ops.end()
 
     def solve(self):
@@ -608,6 +715,7 @@ class SlabMultigrid:
             err_old = err
             done = not (err > self.epsilon and not self.diverged)
             self.it += 1
+        self._flush_pending()
         self.ops.end()
         self.materialize_residual()
         return err

@@ -27,32 +27,58 @@ class HipOps:
         self.stream = torch.cuda.Stream(self.device)
         self._side, self._on_side, self._side_pending = None, False, False
         self._copy = None
+        self._comm, self._on_comm, self._comm_done = None, False, None
 
     # ---- memory / stream plumbing (torch) -------------------------------------------------
-    alloc_skew = int(os.environ.get("MG_ALLOC_SKEW", "0"))  # experiment: bytes of offset between successive arrays
-
     def zeros(self, rows, ld, batch=None):
-        pool_gb = int(os.environ.get("MG_POOL_GB", "0"))  # experiment: all arrays from one allocation
-        if pool_gb:
-            if getattr(self, "_pool", None) is None:
-                self._pool = torch.zeros(pool_gb << 27, dtype=torch.float64, device=self.device)
-                self._pool_off = 0
-            n = rows * ld * (batch or 1)
-            al = int(os.environ.get("MG_POOL_ALIGN", "2097152")) // 8
-            off = (self._pool_off + al - 1) // al * al
-            self._pool_off = off + n
-            v = self._pool[off : off + n]
-            return v.view((rows, ld) if batch is None else (batch, rows, ld))
-        if self.alloc_skew and batch is None and rows * ld * 8 >= (1 << 26):
-            # large arrays start at staggered offsets inside their allocations, so that the row streams of
-            # one pass (x, b, x_out at the same row) do not line up on the same memory channels
-            self._nalloc = getattr(self, "_nalloc", 0) + 1
-            pad = 1 << 18
-            off = (self._nalloc * self.alloc_skew // 8) % pad
-            off -= off % 16
-            flat = torch.zeros(rows * ld + pad, dtype=torch.float64, device=self.device)
-            return flat[off : off + rows * ld].view(rows, ld)
         return torch.zeros((rows, ld) if batch is None else (batch, rows, ld), dtype=torch.float64, device=self.device)
+
+    def placement_spacer(self, rows, ld, verbose=False):
+        """Where in HBM large arrays land changes the streaming rate of the passes over them by several per
+        cent (measured at 32769 x 32769: 8.7 to 9.5 ms per V-cycle depending on how much memory was allocated
+        before the level arrays, freed or not; which offsets are good differs from device to device;
+        tools/placement_probe.py, tools/ab_cycles.py).  This tries offsets 0, 10, .. 120 GiB -- a spacer
+        of that size, then three (rows x ld) arrays as the engine allocates them, three Jacobi sweeps
+        timed -- and returns a spacer tensor of the best size (None for 0 or when memory is short).
+        The caller allocates its arrays and then frees the spacer: the arrays stay where they are."""
+        nbytes = rows * ld * 8
+        if nbytes < (1 << 30):
+            return None
+        free = torch.cuda.mem_get_info(self.device)[0]
+        cands = [g for g in range(0, 130, 10) if (g << 30) + 4 * nbytes + (16 << 30) <= free]
+        if len(cands) < 2:
+            return None
+        results = []
+        for g in cands:
+            sp = arrs = None
+            try:
+                sp = torch.empty(g << 27, dtype=torch.float64, device=self.device) if g else None
+                arrs = [self.zeros(rows, ld) for _ in range(3)]
+            except torch.OutOfMemoryError:  # someone else took the memory meanwhile: not a candidate
+                del sp, arrs
+                torch.cuda.empty_cache()
+                continue
+            del sp
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.begin()
+            self.jacobi(arrs[2], arrs[0], arrs[1], ld, 1, rows - 1, 1.0)
+            ev0.record(self.stream)
+            for k in range(3):
+                self.jacobi(arrs[2], arrs[k & 1], arrs[1 - (k & 1)], ld, 1, rows - 1, 1.0)
+            ev1.record(self.stream)
+            self.stream.synchronize()
+            results.append((ev0.elapsed_time(ev1) / 3, g))
+            del arrs
+            torch.cuda.empty_cache()
+        if not results:
+            return None
+        if verbose:
+            print("placement: ms per sweep by spacer GiB:", " ".join(f"{g}:{t:.3f}" for t, g in results), flush=True)
+        best = min(results)[1]
+        try:
+            return torch.empty(best << 27, dtype=torch.float64, device=self.device) if best else None
+        except torch.OutOfMemoryError:
+            return None
 
     def norm_slots(self):
         return torch.zeros(_lib.NORM_SLOTS, dtype=torch.int64, device=self.device)
@@ -93,9 +119,31 @@ class HipOps:
             self.stream.wait_event(ev)
             self._side_pending = False
 
+    # An exchange whose result is not needed at once can run beside the kernels that follow it: inside
+    # comm_side() the context torch.distributed calls are issued in (ctx()) is a communication stream
+    # that starts after everything enqueued so far on the main sequence; the main sequence goes on
+    # without waiting until comm_join().
+    @contextlib.contextmanager
+    def comm_side(self):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(self.device)
+        self._comm.wait_event(self.mark())
+        self._on_comm = True
+        try:
+            yield
+        finally:
+            self._on_comm = False
+            self._comm_done = torch.cuda.Event()
+            self._comm_done.record(self._comm)
+
+    def comm_join(self):
+        if self._comm_done is not None:
+            self.stream.wait_event(self._comm_done)
+            self._comm_done = None
+
     def ctx(self):
         """Context in which torch ops and torch.distributed calls are ordered with the kernels."""
-        return torch.cuda.stream(self.stream)
+        return torch.cuda.stream(self._comm if self._on_comm else self.stream)
 
     def begin(self):
         """Order this object's stream after whatever the caller enqueued on torch's current stream."""

@@ -157,19 +157,22 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, dist_min_rows=None):
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, dist_min_rows=None, **kw):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         eng, errs, x, r = _engine_run(gny, gnx, n_para, h, b, world, rank, cycles, fused=fused,
-                                      dist_min_rows=dist_min_rows)
+                                      dist_min_rows=dist_min_rows, **kw)
         # communication rounds of one more cycle (its last pass also stores r: no extra round)
         before = eng.comm.rounds
         eng.cycles(1)
         assert eng.comm.rounds - before == eng.rounds_per_cycle(), (eng.n_dist, eng.comm.rounds - before)
         assert eng.rounds_per_cycle() <= exchanges_per_cycle(eng.n_dist, fused)
+        if kw.get("overlap_min_rows") == 1:  # the finest pass of every cycle at least is cut (and presmooth's)
+            assert eng.split_passes >= cycles + 1 and eng._pending is None
+            q.put(("splits", rank, eng.split_passes))
         q.put((rank, errs, x, r))
         dist.barrier()
     finally:
@@ -185,6 +188,24 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, di
                                                         (4, 257, 33, 2, False),
                                                         (8, 1025, 65, 4, True)], ids=str)
 def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused, dist_min_rows):
+    _gloo_run_equals_oracle(world, gny, gnx, n_para, fused, dist_min_rows)
+
+
+# overlap_min_rows=1: every pass that follows a halo exchange is cut into interior rows (enqueued before
+# the exchange is waited for) and the rows at both slab ends, wherever the slab is tall enough for the
+# cut; right-hand-side halos are exchanged by the pass that reads them first.  Same values, same rounds.
+@pytest.mark.parametrize("world,gny,gnx,n_para,dist_min_rows,recompute",
+                         [(2, 129, 65, 3, None, True), (2, 257, 129, 3, 8, True), (4, 257, 33, 2, 8, True),
+                          (8, 1025, 65, 4, 8, True), (2, 513, 33, 4, 8, True), (2, 513, 33, 4, 8, False),
+                          (4, 513, 65, 3, 8, False)], ids=str)
+def test_gloo_ranks_with_split_passes_equal_global_oracle(world, gny, gnx, n_para, dist_min_rows, recompute):
+    splits = _gloo_run_equals_oracle(world, gny, gnx, n_para, True, dist_min_rows, overlap_min_rows=1,
+                                     recompute_presmoothing=recompute)
+    if (gny - 1) // world >= 256:  # tall slabs: coarser levels are cut too (descent and ascent passes)
+        assert min(splits.values()) > 2 * 5
+
+
+def _gloo_run_equals_oracle(world, gny, gnx, n_para, fused, dist_min_rows, **kw):
     b = _rhs(gny, gnx, 7)
     h = 0.37
     cycles = 3
@@ -194,13 +215,17 @@ def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused, dist_min
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows))
-             for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows),
+                         kwargs=kw) for rk in range(world)]
     for p in procs:
         p.start()
-    out = {}
-    for _ in range(world):
-        rank, errs, x, r = q.get(timeout=240)
+    out, splits = {}, {}
+    while len(out) < world:
+        msg = q.get(timeout=240)
+        if msg[0] == "splits":
+            splits[msg[1]] = msg[2]
+            continue
+        rank, errs, x, r = msg
         out[rank] = (errs, x, r)
     for p in procs:
         p.join(timeout=60)
@@ -211,6 +236,7 @@ def test_gloo_ranks_equal_global_oracle(world, gny, gnx, n_para, fused, dist_min
         assert out[k][0] == ref.err_hist.tolist()  # every rank sees the global max-norm
     assert np.array_equal(x, ref.x)
     assert np.array_equal(r, ref.r)
+    return splits
 
 
 def test_batch_of_problems_equals_independent_solves():

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows):
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows, kw=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -31,13 +31,15 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_mi
         from multigrid_amd.engine import SlabMultigrid
         # dead whole-domain levels every cycle for the larger grids: rank 0 runs them as a graph on a side stream
         eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=world, rank=rank, fused=fused, eager_dead_levels=gny > 300,
-                            dist_min_rows=dist_min_rows, recompute_min_nx=0, recompute_min_blocks=0)
+                            dist_min_rows=dist_min_rows, recompute_min_nx=0, recompute_min_blocks=0, **(kw or {}))
         assert eng.comm.staged
         R = eng.plan.levels[0].rows
         a, e = eng.owned_rows()
         eng.set_b_rows(torch.from_numpy(b[rank * R : rank * R + (e - a)]).cuda())
         eng.presmooth()
         errs = eng.cycles(cycles)
+        if kw and kw.get("overlap_min_rows") == 1:  # the finest pass of every cycle at least was cut
+            assert eng.split_passes >= cycles + 1 and eng._pending is None
         x = eng.local_rows(eng.x0).cpu().numpy()
         r = eng.local_rows(eng.r0).cpu().numpy()
         q.put((rank, errs, x, r))
@@ -51,6 +53,19 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_mi
                                                         (3, 769, 300 * 4 + 1, 2, True), (4, 1025, 513, 5, False)], ids=str)
 @pytest.mark.parametrize("dist_min_rows", [8, 64])
 def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para, fused, dist_min_rows):
+    _run(world, gny, gnx, n_para, fused, dist_min_rows)
+
+
+# overlap_min_rows=1: passes that follow a halo exchange are cut into interior rows, launched beside the
+# exchange (which runs on the communication stream), and the rows at the slab ends, launched after it
+@pytest.mark.parametrize("world,gny,gnx,n_para,dist_min_rows,recompute",
+                         [(2, 257, 257, 3, 8, True), (4, 1025, 513, 5, 8, True), (4, 1025, 513, 5, 64, False),
+                          (3, 769, 1201, 2, 8, True), (2, 2049, 1025, 5, 8, True), (2, 2049, 1025, 5, 8, False)], ids=str)
+def test_ranks_with_split_passes_equal_oracle(world, gny, gnx, n_para, dist_min_rows, recompute):
+    _run(world, gny, gnx, n_para, True, dist_min_rows, dict(overlap_min_rows=1, recompute_presmoothing=recompute))
+
+
+def _run(world, gny, gnx, n_para, fused, dist_min_rows, kw=None):
     import torch.multiprocessing as mp
     rng = np.random.default_rng(1)
     b = rng.standard_normal((gny, gnx))
@@ -63,7 +78,7 @@ def test_ranks_sharing_one_gpu_equal_oracle(world, gny, gnx, n_para, fused, dist
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows))
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows, kw))
              for rk in range(world)]
     for p in procs:
         p.start()

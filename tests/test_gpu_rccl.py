@@ -49,6 +49,13 @@ def _worker(port, q):
         batch = comm.prepare(sends, recvs)
         comm.run(batch)
         comm.run(batch)  # a prepared batch is issued every cycle
+        # the same batch on the communication stream, beside a kernel of the main sequence (split passes)
+        with ops.ctx():
+            scratch = torch.ones(1 << 20, dtype=torch.float64, device="cuda")
+        with ops.comm_side():
+            comm.run(batch)
+        ops.zero_(scratch)
+        ops.comm_join()
         with ops.ctx():
             inp = x[H:H + rows]
             out = torch.zeros(rows + 5, ld, dtype=torch.float64, device="cuda")
@@ -84,7 +91,7 @@ def _worker(port, q):
             runs.append((errs, eng.local_rows(eng.x0).cpu().numpy()))
             eng.close()
         graphs_ok = runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
-        ok = (bool(torch.equal(x, want)), bool(torch.equal(out[2:2 + rows], inp)), bool(out[:2].eq(0).all() and out[2 + rows:].eq(0).all()),
+        ok = (bool(torch.equal(x, want)) and bool(scratch.eq(0).all()), bool(torch.equal(out[2:2 + rows], inp)), bool(out[:2].eq(0).all() and out[2 + rows:].eq(0).all()),
               bool(torch.equal(slots, before)), graphs_ok)
         q.put((ok, per_round))
         dist.barrier()

@@ -21,7 +21,12 @@ def main():
     n = args.exp
     dummy = [torch.zeros(int(os.environ.get("MG_DUMMY_GB", "0")) << 27, dtype=torch.float64, device="cuda")]  # experiment: where the arrays land
     N = 2 ** (n + 1) + 1
-    eng = SlabMultigrid(N, N, 8, 20.0 / 2 ** (n + 1), 0.025, eager_dead_levels=True)
+    eng = SlabMultigrid(N, N, 8, 20.0 / 2 ** (n + 1), 0.025, eager_dead_levels=True,
+                        tune_placement="verbose" if os.environ.get("MG_TUNE_PLACEMENT") else False)
+    if os.environ.get("MG_DUMMY_FREE"):
+        dummy.clear()
+        torch.cuda.empty_cache()
+    print("x0, b0 at GiB", round(eng.x0.data_ptr() / 2 ** 30, 2), round(eng.b0.data_ptr() / 2 ** 30, 2), "free GiB", round(torch.cuda.mem_get_info()[0] / 2 ** 30, 1), flush=True)
     bench.fill_rhs(eng, torch, n, 0)
     eng.presmooth()
     eng.cycles(2)
