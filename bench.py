@@ -278,6 +278,8 @@ def main():
                 "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph), "fused_passes": bool(eng.fused), "recompute_presmoothing": bool(eng.recompute_presmoothing and eng.fused),
                 "placement_spacer_gib": eng.placement_gib,
                 "halo_rows": eng.plan.halo, "distributed_levels": eng.n_dist if world > 1 else None,
+                "exchange_overlap": ({"min_rows_per_rank": eng.overlap_min_rows, "passes_cut": eng.split_passes,
+                                      "rounds_per_cycle": eng.rounds_per_cycle()} if world > 1 else None),
                 "dead_whole_domain_levels": "computed every cycle" if eng.eager_dead_levels else "on demand", "backend": args.backend if world > 1 else None,
             },
             "roofline": {

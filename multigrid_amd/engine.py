@@ -125,14 +125,13 @@ class SlabMultigrid:
         z = (lambda rows, ld: ops.zeros(rows, ld, batch)) if batch is not None else ops.zeros
         # Jacobi levels: two x arrays (ping-pong), b, r.  b has one more level (the staging level).
         LV = self.lv
-        # tune_placement: try where in HBM the finest level's arrays stream fastest (HipOps.placement_spacer)
-        spacer = None
-        self.placement_gib = None  # GiB skipped in front of the level arrays (None: placement not tuned)
-        if tune_placement and batch is None and hasattr(ops, "placement_spacer"):
-            spacer = ops.placement_spacer(LV[0].ny, LV[0].ld, verbose=tune_placement == "verbose")
-            self.placement_gib = 0 if spacer is None else spacer.numel() >> 27
-        # the finest level's arrays first, in this order (the placement search allocates the same way)
-        fin = [z(LV[0].ny, LV[0].ld) for _ in range(4)]
+        # the finest level's arrays first: x (two, ping-pong), b, r
+        self.placement_gib = None  # GiB skipped in front of them (None: placement not tuned)
+        fin = None
+        if tune_placement and batch is None and getattr(ops, "supports_placement", False) and self.fused:
+            fin = self._place_finest(verbose=tune_placement == "verbose")
+        if fin is None:
+            fin = [z(LV[0].ny, LV[0].ld) for _ in range(4)]
         self._xa = [fin[0]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
         self._xb = [fin[1]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
         self.b = [fin[2]] + [z(L.ny, L.ld) for L in LV[1:]]
@@ -157,9 +156,6 @@ class SlabMultigrid:
             self.xw.append(z(W.ny, W.ld))
             self.bw.append(z(W.ny, W.ld))
             self.rw.append(z(W.ny, W.ld))
-        if spacer is not None:  # the arrays stay where they are
-            del spacer
-            torch.cuda.empty_cache()
         # Several ranks, fused passes: a pass that follows a halo exchange is cut into the rows that depend
         # on owned rows only -- launched at once, beside the exchange, which runs on a stream of its own --
         # and the few rows at both slab ends, launched once the halo rows have arrived.  Done on levels
@@ -176,6 +172,59 @@ class SlabMultigrid:
         self._r0_stale = False
         # store the finest residual in every cycle's pass instead of once at the end of solve()/cycles()
         self.store_residual_every_cycle = store_residual_every_cycle
+
+    def _place_finest(self, verbose=False):
+        """Where in HBM the finest level's arrays land changes the rate of the pass that streams them by
+        several per cent (measured at 32769 x 32769: 5.8 to 6.4 ms for the same launch from one process
+        to the next on one device, and with the amount of memory allocated in front of the arrays; which
+        offsets are good differs from device to device).  So set-up samples placements: for 0, 10, ..
+        120 GiB allocated in front (and released again), the four arrays are allocated and the finest
+        pass of the cycle is timed on them; the set with the fastest pass is the one that is kept --
+        the arrays that were timed, not a second allocation of the same size.  None when the level is
+        small (< 1 GiB per array) or memory is short."""
+        ops, L, Lc = self.ops, self.lv[0], self.plan.levels[1]
+        nbytes = L.ny * L.ld * 8
+        if nbytes < (1 << 30):
+            return None
+        free = torch.cuda.mem_get_info(ops.device)[0]
+        # the set kept so far + the set on trial + the spacer, and room for the other levels
+        cands = [g for g in range(0, 130, 10) if (g << 30) + 10 * nbytes + (8 << 30) <= free]
+        if len(cands) < 2:
+            return None
+        crs, cb, norm = ops.zeros(Lc.ny, self.lv[1].ld), ops.zeros(Lc.ny, Lc.ld), ops.norm_slots()
+        best, log = None, []
+        for g in cands:
+            sp = arrs = None
+            try:
+                sp = torch.empty(g << 27, dtype=torch.float64, device=ops.device) if g else None
+                arrs = [ops.zeros(L.ny, L.ld) for _ in range(4)]
+            except torch.OutOfMemoryError:  # someone else took the memory meanwhile: not a candidate
+                del sp, arrs
+                torch.cuda.empty_cache()
+                continue
+            del sp
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ops.begin()
+            for k in range(4):  # the cycle's launch on the finest level; the first one is not timed
+                ops.smooth_fused(arrs[2], arrs[k & 1], arrs[1 - (k & 1)], None, crs, L.nx, self.lv[1].nx, L.t0, L.t1,
+                                 L.fix_lo, L.fix_hi, L.oj, self.N2, L.h, norm, cb, Lc.nx, Lc.t0, Lc.t1,
+                                 omega=self.jacobi_omega)
+                if k == 0:
+                    ev[0].record(ops.stream)
+            ev[1].record(ops.stream)
+            ops.stream.synchronize()
+            t = ev[0].elapsed_time(ev[1]) / 3
+            log.append((g, t))
+            if best is None or t < best[0]:
+                best = (t, arrs, g)
+            del arrs
+            torch.cuda.empty_cache()
+        if verbose:
+            print("placement: ms per finest pass by GiB in front:", " ".join(f"{g}:{t:.3f}" for g, t in log), flush=True)
+        if best is None:
+            return None
+        self.placement_gib = best[2]
+        return best[1]
 
     # ------------------------------------------------------------------ data access
     @property

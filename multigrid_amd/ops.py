@@ -33,52 +33,7 @@ class HipOps:
     def zeros(self, rows, ld, batch=None):
         return torch.zeros((rows, ld) if batch is None else (batch, rows, ld), dtype=torch.float64, device=self.device)
 
-    def placement_spacer(self, rows, ld, verbose=False):
-        """Where in HBM large arrays land changes the streaming rate of the passes over them by several per
-        cent (measured at 32769 x 32769: 8.7 to 9.5 ms per V-cycle depending on how much memory was allocated
-        before the level arrays, freed or not; which offsets are good differs from device to device;
-        tools/placement_probe.py, tools/ab_cycles.py).  This tries offsets 0, 10, .. 120 GiB -- a spacer
-        of that size, then three (rows x ld) arrays as the engine allocates them, three Jacobi sweeps
-        timed -- and returns a spacer tensor of the best size (None for 0 or when memory is short).
-        The caller allocates its arrays and then frees the spacer: the arrays stay where they are."""
-        nbytes = rows * ld * 8
-        if nbytes < (1 << 30):
-            return None
-        free = torch.cuda.mem_get_info(self.device)[0]
-        cands = [g for g in range(0, 130, 10) if (g << 30) + 4 * nbytes + (16 << 30) <= free]
-        if len(cands) < 2:
-            return None
-        results = []
-        for g in cands:
-            sp = arrs = None
-            try:
-                sp = torch.empty(g << 27, dtype=torch.float64, device=self.device) if g else None
-                arrs = [self.zeros(rows, ld) for _ in range(3)]
-            except torch.OutOfMemoryError:  # someone else took the memory meanwhile: not a candidate
-                del sp, arrs
-                torch.cuda.empty_cache()
-                continue
-            del sp
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.begin()
-            self.jacobi(arrs[2], arrs[0], arrs[1], ld, 1, rows - 1, 1.0)
-            ev0.record(self.stream)
-            for k in range(3):
-                self.jacobi(arrs[2], arrs[k & 1], arrs[1 - (k & 1)], ld, 1, rows - 1, 1.0)
-            ev1.record(self.stream)
-            self.stream.synchronize()
-            results.append((ev0.elapsed_time(ev1) / 3, g))
-            del arrs
-            torch.cuda.empty_cache()
-        if not results:
-            return None
-        if verbose:
-            print("placement: ms per sweep by spacer GiB:", " ".join(f"{g}:{t:.3f}" for t, g in results), flush=True)
-        best = min(results)[1]
-        try:
-            return torch.empty(best << 27, dtype=torch.float64, device=self.device) if best else None
-        except torch.OutOfMemoryError:
-            return None
+    supports_placement = True  # SlabMultigrid(tune_placement=True) may time placements of its arrays
 
     def norm_slots(self):
         return torch.zeros(_lib.NORM_SLOTS, dtype=torch.int64, device=self.device)
