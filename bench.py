@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-fused", action="store_true", help="one kernel per operation instead of fused passes")
     ap.add_argument("--no-recompute", action="store_true",
                     help="coarse levels store x after the pre-smoothing instead of recomputing it in the post-smoothing pass")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the (2**(n+1)+1)^2 grid is cut into N slabs instead of growing by N times "
+                         "the rows (the default, weak scaling)")
     ap.add_argument("--no-tune-placement", action="store_true",
                     help="allocate the level arrays where the allocator puts them instead of timing a few "
                          "placements of the finest level's arrays at set-up and keeping the fastest")
@@ -171,7 +174,7 @@ def main():
     from multigrid_amd.levels import choose_n_para
     n = args.n
     gnx = 2 ** (n + 1) + 1
-    gny = world * 2 ** (n + 1) + 1
+    gny = (1 if args.strong else world) * 2 ** (n + 1) + 1
     n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=min(8, n - 1))
     if not n_para:
         sys.exit(f"no admissible number of Jacobi levels for a {gny}x{gnx} grid on {world} ranks")
@@ -269,9 +272,9 @@ def main():
         out = {
             "metric": "unknowns*V-cycles/s", "value": unknowns * args.steps / dt, "unit": "unknowns*V-cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": (f"{gny}x{gnx} fp64 Poisson V-cycle ({gnx}x{gnx} per GPU), test.py 8-vortex RHS" if not args.batch
+                "workload": (f"{gny}x{gnx} fp64 Poisson V-cycle ({(gny - 1) // world + 1}x{gnx} per GPU), test.py 8-vortex RHS" if not args.batch
                              else f"{args.batch} independent {gny}x{gnx} fp64 Poisson V-cycles in one batch, test.py 8-vortex RHS"),
                 "n": n, "n_para": n_para, "grid": [gny, gnx], "batch": args.batch or None, "unknowns": unknowns,
                 "coarse_ordering": args.ordering, "jacobi_omega": args.jacobi_omega, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],

@@ -249,9 +249,14 @@ int mg_graph_destroy(void *graph_exec);
  *                      MG_SOLVER_LAZY_DEAD_LEVELS   skip the whole-domain levels below the first,
  *                                                   which nothing reads under the reference's loop
  *                                                   bounds (ignored with FIX_COARSE_ASCENT)
+ *                      MG_SOLVER_TUNE_PLACEMENT     create samples where in device memory the finest
+ *                                                   level's arrays stream fastest (grids of >= 1 GiB
+ *                                                   per array; a few seconds; results unchanged)
  *   mg_solver_set      "jacobi_omega" (0 < w <= 1, 1 = the reference's sweep), "max_cycles"
  *                      (default 100, :270), "recompute_min_nx" / "recompute_min_blocks" (size from
  *                      which a coarse level recomputes its pre-smoothing instead of storing it)
+ *   mg_solver_placement  GiB of memory create put in front of the finest arrays under
+ *                      MG_SOLVER_TUNE_PLACEMENT (-1: placement was not tuned)
  *   mg_solver_upload   finest-level b (MG_SOLVER_B) or x (MG_SOLVER_X: initial guess and Dirichlet
  *                      boundary values) from a host or device array of gny rows, src_ld apart
  *   mg_solver_solve    solve() (:232-348): one sweep + residual, then V-cycles until max|r| <= eps,
@@ -270,10 +275,12 @@ typedef struct mg_solver mg_solver;
 #define MG_SOLVER_REDBLACK 2
 #define MG_SOLVER_NO_GRAPH 4
 #define MG_SOLVER_LAZY_DEAD_LEVELS 8
+#define MG_SOLVER_TUNE_PLACEMENT 16
 enum { MG_SOLVER_X = 0, MG_SOLVER_B = 1, MG_SOLVER_R = 2, MG_SOLVER_XW = 3, MG_SOLVER_BW = 4, MG_SOLVER_RW = 5 };
 int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0, int flags, mg_solver **out);
 int mg_solver_destroy(mg_solver *s);
 int mg_solver_set(mg_solver *s, const char *key, double value);
+int mg_solver_placement(mg_solver *s, int *gib);
 int mg_solver_upload(mg_solver *s, int which, const double *src, int64_t src_ld);
 int mg_solver_download(mg_solver *s, int which, int level, double *dst, int64_t dst_ld);
 int mg_solver_array(mg_solver *s, int which, int level, double **device_ptr, int64_t *ny, int64_t *nx, int64_t *ld);

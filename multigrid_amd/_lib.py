@@ -56,6 +56,7 @@ SIGNATURES = {
     "mg_solver_create": ([_i, _i, _n, _d, _n, C.POINTER(_p)], _n),
     "mg_solver_destroy": ([_p], _n),
     "mg_solver_set": ([_p, C.c_char_p, _d], _n),
+    "mg_solver_placement": ([_p, C.POINTER(_n)], _n),
     "mg_solver_upload": ([_p, _n, _p, _i], _n),
     "mg_solver_download": ([_p, _n, _n, _p, _i], _n),
     "mg_solver_array": ([_p, _n, _n, C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _n),
@@ -64,7 +65,7 @@ SIGNATURES = {
     "mg_solver_solve": ([_p, _d, C.POINTER(_n), C.POINTER(_d)], _n),
     "mg_solver_history": ([_p, C.POINTER(_d), _n, C.POINTER(_n), C.POINTER(_n)], _n),
 }
-SOLVER_FIX_COARSE_ASCENT, SOLVER_REDBLACK, SOLVER_NO_GRAPH, SOLVER_LAZY_DEAD_LEVELS = 1, 2, 4, 8
+SOLVER_FIX_COARSE_ASCENT, SOLVER_REDBLACK, SOLVER_NO_GRAPH, SOLVER_LAZY_DEAD_LEVELS, SOLVER_TUNE_PLACEMENT = 1, 2, 4, 8, 16
 SOLVER_ARRAYS = {"x": 0, "b": 1, "r": 2, "xw": 3, "bw": 4, "rw": 5}
 
 

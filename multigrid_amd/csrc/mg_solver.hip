@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "mg_common.h"
@@ -55,6 +56,7 @@ struct mg_solver {
     bool r_stale;  // the finest residual array is older than x
     int it;
     bool diverged;
+    int placement_gib; // GiB in front of the finest arrays chosen by MG_SOLVER_TUNE_PLACEMENT, -1: not tuned
     std::vector<double> hist;
 };
 
@@ -255,6 +257,65 @@ int materialize_residual(mg_solver *s)
 
 int read_err(mg_solver *s, double *err) { return mg_norm_read((const uint64_t *)s->norm, err, s->stream); }
 
+// Where in HBM the finest level's four arrays land changes the rate of the pass that streams them by
+// several per cent (32769 x 32769: 5.6 to 6.4 ms for the same launch, from one process to the next
+// and with the amount of memory allocated in front of the arrays).  With MG_SOLVER_TUNE_PLACEMENT
+// create samples placements: for 0, 10, .. 120 GiB allocated in front and released again, the four
+// arrays are allocated and zeroed and the cycle's finest pass is timed on them; the set with the
+// fastest pass is kept (the arrays that were timed).  fin[] stays null when the level is small
+// (< 1 GiB per array), memory is short or anything fails: create then allocates as usual.
+void place_finest(mg_solver *s, double *fin[4])
+{
+    const i64 ny = s->gny, nx = s->gnx, ld = pitch(nx), n = ny * ld;
+    const size_t bytes = (size_t)n * sizeof(double);
+    for (int k = 0; k < 4; ++k) fin[k] = nullptr;
+    size_t free_b = 0, total_b = 0;
+    if (bytes < ((size_t)1 << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const i64 cny = ((ny - 1) >> 1) + 1, cnx = ((nx - 1) >> 1) + 1, cld = pitch(cnx); // the next level, Jacobi or whole-domain
+    const size_t cbytes = (size_t)(cny * cld) * sizeof(double);
+    double *crs = nullptr, *cb = nullptr;
+    u64 *norm = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ready = hipMalloc((void **)&crs, cbytes) == hipSuccess && hipMalloc((void **)&cb, cbytes) == hipSuccess &&
+                 hipMalloc((void **)&norm, MG_NORM_SLOTS * sizeof(u64)) == hipSuccess &&
+                 hipMemsetAsync(crs, 0, cbytes, s->stream) == hipSuccess && hipMemsetAsync(cb, 0, cbytes, s->stream) == hipSuccess &&
+                 hipMemsetAsync(norm, 0, MG_NORM_SLOTS * sizeof(u64), s->stream) == hipSuccess &&
+                 hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    float best = 0;
+    for (int g = 0; ready && g <= 120; g += 10) {
+        // the set kept so far + the set on trial + the memory in front, and room for the other levels
+        if (((size_t)g << 30) + 10 * bytes + ((size_t)8 << 30) > free_b) break;
+        void *front = nullptr;
+        double *a[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = g == 0 || hipMalloc(&front, (size_t)g << 30) == hipSuccess;
+        for (int k = 0; k < 4 && ok; ++k)
+            ok = hipMalloc((void **)&a[k], bytes) == hipSuccess && hipMemsetAsync(a[k], 0, bytes, s->stream) == hipSuccess;
+        if (front) (void)hipFree(front);
+        float ms = 0;
+        for (int k = 0; k < 4 && ok; ++k) { // the launch of finest_pass; the first one is not timed
+            ok = !mg_smooth_fused_restrict(a[2], a[k & 1], a[1 - (k & 1)], nullptr, crs, ny, nx, ld, cny, cnx, cld, 1, ny - 1, 0,
+                                           ny - 1, 0, N2, s->h0, 1.0, (uint64_t *)norm, cb, cny, cnx, cld, 1, cny - 1, 1, 0, 0, 0,
+                                           s->stream);
+            if (k == 0) ok = ok && hipEventRecord(e0, s->stream) == hipSuccess;
+        }
+        ok = ok && hipEventRecord(e1, s->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        const bool keep = ok && (!fin[0] || ms < best);
+        for (int k = 0; k < 4; ++k) {
+            if (keep) std::swap(a[k], fin[k]);
+            if (a[k]) (void)hipFree(a[k]);
+        }
+        if (keep) best = ms, s->placement_gib = g;
+        if (!ok) (void)hipGetLastError(); // e.g. a refused allocation: not a candidate
+    }
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (crs) (void)hipFree(crs);
+    if (cb) (void)hipFree(cb);
+    if (norm) (void)hipFree(norm);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+}
+
 } // namespace
 
 extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0, int flags, mg_solver **out)
@@ -270,7 +331,8 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
     MG_REQUIRE(((gny - 1) >> n_para) >= 2 && ((gnx - 1) >> n_para) >= 2,
                "mg_solver_create: the first whole-domain level needs at least 2 cells per side");
     MG_REQUIRE(h0 > 0, "mg_solver_create: mesh width must be positive");
-    MG_REQUIRE((flags & ~(MG_SOLVER_FIX_COARSE_ASCENT | MG_SOLVER_REDBLACK | MG_SOLVER_NO_GRAPH | MG_SOLVER_LAZY_DEAD_LEVELS)) == 0,
+    MG_REQUIRE((flags & ~(MG_SOLVER_FIX_COARSE_ASCENT | MG_SOLVER_REDBLACK | MG_SOLVER_NO_GRAPH | MG_SOLVER_LAZY_DEAD_LEVELS |
+                          MG_SOLVER_TUNE_PLACEMENT)) == 0,
                "mg_solver_create: unknown flag bits in %d", flags);
     mg_solver *s = new (std::nothrow) mg_solver();
     MG_REQUIRE(s, "mg_solver_create: out of host memory");
@@ -282,7 +344,7 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
     s->omega = 1.0, s->max_cycles = 100; // :270
     s->recompute_min_nx = 1024, s->recompute_min_blocks = 1024;
     s->norm = nullptr, s->stream = s->side = nullptr, s->fork = s->join = nullptr;
-    s->cur0 = 0, s->r_stale = true, s->it = 0, s->diverged = false;
+    s->cur0 = 0, s->r_stale = true, s->it = 0, s->diverged = false, s->placement_gib = -1;
     for (int a = 0; a < 2; ++a) s->graphs[a][0] = s->graphs[a][1] = nullptr, s->graph_end_cur[a] = 0;
     int rc = 1;
     do {
@@ -295,13 +357,23 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
             break;
         }
         bool ok = true;
+        double *fin[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (flags & MG_SOLVER_TUNE_PLACEMENT) {
+            place_finest(s, fin);
+            for (int k = 0; k < 4; ++k)
+                if (fin[k]) s->allocs.push_back(fin[k]);
+        }
         for (int l = 0; l < n_para && ok; ++l) {
             JLevel L;
             L.ny = ((gny - 1) >> l) + 1, L.nx = ((gnx - 1) >> l) + 1, L.ld = pitch(L.nx);
             L.h = h0 * (double)((i64)1 << l); // h_sb, :195
             L.r = nullptr, L.recompute = false;
-            ok = !dev_alloc(s, &L.xa, L.ny * L.ld) && !dev_alloc(s, &L.xb, L.ny * L.ld) && !dev_alloc(s, &L.b, L.ny * L.ld);
-            if (ok && l == 0) ok = !dev_alloc(s, &L.r, L.ny * L.ld);
+            if (l == 0 && fin[0]) { // placed (and left all zero) by place_finest
+                L.xa = fin[0], L.xb = fin[1], L.b = fin[2], L.r = fin[3];
+            } else {
+                ok = !dev_alloc(s, &L.xa, L.ny * L.ld) && !dev_alloc(s, &L.xb, L.ny * L.ld) && !dev_alloc(s, &L.b, L.ny * L.ld);
+                if (ok && l == 0) ok = !dev_alloc(s, &L.r, L.ny * L.ld);
+            }
             s->lv.push_back(L);
         }
         for (int l = n_para; ok; ++l) { // whole-domain levels down to 3 x 3 (:207-219)
@@ -340,6 +412,14 @@ extern "C" int mg_solver_destroy(mg_solver *s)
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+    return 0;
+}
+
+extern "C" int mg_solver_placement(mg_solver *s, int *gib)
+{
+    if (check_device(s, "mg_solver_placement")) return 1;
+    MG_REQUIRE(gib, "mg_solver_placement: null output");
+    *gib = s->placement_gib;
     return 0;
 }
 

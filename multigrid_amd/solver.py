@@ -15,11 +15,13 @@ from ._lib import MgError, check
 
 class NativeSolver:
     def __init__(self, gny, gnx, n_para, h0, *, fix_coarse_ascent=False, coarse_ordering="lexicographic", use_graph=True,
-                 eager_dead_levels=True, jacobi_omega=1.0, max_cycles=100, recompute_min_nx=None, recompute_min_blocks=None):
+                 eager_dead_levels=True, jacobi_omega=1.0, max_cycles=100, recompute_min_nx=None, recompute_min_blocks=None,
+                 tune_placement=False):
         self.L = _lib.lib()
         flags = (_lib.SOLVER_FIX_COARSE_ASCENT if fix_coarse_ascent else 0) | \
                 (_lib.SOLVER_REDBLACK if coarse_ordering == "redblack" else 0) | \
-                (0 if use_graph else _lib.SOLVER_NO_GRAPH) | (0 if eager_dead_levels else _lib.SOLVER_LAZY_DEAD_LEVELS)
+                (0 if use_graph else _lib.SOLVER_NO_GRAPH) | (0 if eager_dead_levels else _lib.SOLVER_LAZY_DEAD_LEVELS) | \
+                (_lib.SOLVER_TUNE_PLACEMENT if tune_placement else 0)
         h = C.c_void_p()
         check(self.L.mg_solver_create(gny, gnx, n_para, h0, flags, C.byref(h)))
         self._h = h
@@ -33,6 +35,13 @@ class NativeSolver:
             self.set("recompute_min_nx", recompute_min_nx)
         if recompute_min_blocks is not None:
             self.set("recompute_min_blocks", recompute_min_blocks)
+
+    @property
+    def placement_gib(self):
+        """GiB of memory put in front of the finest arrays by tune_placement; None: placement not tuned."""
+        g = C.c_int()
+        check(self.L.mg_solver_placement(self._h, C.byref(g)))
+        return None if g.value < 0 else g.value
 
     def set(self, key, value):
         check(self.L.mg_solver_set(self._h, key.encode(), float(value)))

@@ -173,6 +173,15 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused=True, di
         if kw.get("overlap_min_rows") == 1:  # the finest pass of every cycle at least is cut (and presmooth's)
             assert eng.split_passes >= cycles + 1 and eng._pending is None
             q.put(("splits", rank, eng.split_passes))
+            # solve() with a cap of as many cycles (epsilon = 0 is never reached) is the same sequence
+            eng2 = SlabMultigrid(gny, gnx, n_para, h, 0.0, ops=OracleOps(), world=world, rank=rank, fused=fused,
+                                 dist_min_rows=dist_min_rows, max_cycles=cycles, recompute_min_nx=0,
+                                 recompute_min_blocks=0, **kw)
+            a, e = eng2.owned_rows()
+            eng2.set_b_rows(torch.from_numpy(b[rank * eng2.plan.levels[0].rows :][: e - a]))
+            assert eng2.solve() == errs[-1] and eng2.it == cycles and eng2._pending is None
+            assert np.array_equal(eng2.local_rows(eng2.x0).numpy(), x)
+            assert np.array_equal(eng2.local_rows(eng2.r0).numpy(), r)
         q.put((rank, errs, x, r))
         dist.barrier()
     finally:

@@ -38,7 +38,10 @@ def _engine(n, n_para, **kw):
 def test_fused_graph_equals_separate_kernels_at_32769():
     import torch
     n, n_para = 14, 8
-    a = _engine(n, n_para, eager_dead_levels=True)
+    # tune_placement: set-up times the finest pass on several placements of the finest arrays and keeps
+    # the arrays of the fastest one; they must come out of it zeroed and laid out like any others
+    a = _engine(n, n_para, eager_dead_levels=True, tune_placement=True)
+    assert a.placement_gib is not None
     a.presmooth()
     ea = a.cycles(2)
     xa = a.x0.clone()
