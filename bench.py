@@ -42,8 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--exp", dest="n", type=int, default=14, help="grid is (2**(n+1)+1) columns wide; 14 -> 32769")
     ap.add_argument("--jacobi-levels", dest="n_para", type=int, default=0,
-                    help="number of Jacobi (slab-distributed) levels; 0 = 8, or more where the first whole-domain level "
-                         "(which grows with the rank count) would leave the single-wave SSOR kernel otherwise: 9, 10, 11 on 2, 4, 8 ranks")
+                    help="number of Jacobi levels; 0 = n - 4, the proportion of the reference's own run (n = 8, n_para = 4: "
+                         "a 33 x 33 first whole-domain level), or more where that level, which grows with the rank "
+                         "count, would leave the single-wave SSOR kernel otherwise (10, 10, 10, 11 on 1, 2, 4, 8 ranks at n = 14)")
     ap.add_argument("--ordering", default="lexicographic", choices=["lexicographic", "redblack"])
     ap.add_argument("--roofline-iters", type=int, default=20)
     ap.add_argument("--cpu-exp", dest="cpu_n", type=int, default=12, help="grid exponent of the CPU baseline sample")
@@ -175,7 +176,9 @@ def main():
     n = args.n
     gnx = 2 ** (n + 1) + 1
     gny = (1 if args.strong else world) * 2 ** (n + 1) + 1
-    n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=min(8, n - 1))
+    # as many Jacobi levels as leave the reference's own coarse size (test/test.py: n = 8, n_para = 4, a 33 x 33
+    # first whole-domain level): the chain of small passes is a little longer, the serial SSOR much shorter
+    n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=max(1, n - 4))
     if not n_para:
         sys.exit(f"no admissible number of Jacobi levels for a {gny}x{gnx} grid on {world} ranks")
     args.n_para = n_para
