@@ -370,9 +370,10 @@ class SlabMultigrid:
         H, R = L.halo, L.rows
         m = D + 2 + (D & 1)
         a, e = H + m, H + R - m
-        with self.ops.comm_side():
+        ready = self.ops.mark()         # the rows to be sent are final here
+        launch(a, e)                    # enqueued first: the GPU has work while the host sets the exchange up
+        with self.ops.comm_side(ready):
             self._exchange(items)
-        launch(a, e)
         self.ops.comm_join()
         launch(L.t0, a)
         launch(e, L.t1)

@@ -76,13 +76,13 @@ class HipOps:
 
     # An exchange whose result is not needed at once can run beside the kernels that follow it: inside
     # comm_side() the context torch.distributed calls are issued in (ctx()) is a communication stream
-    # that starts after everything enqueued so far on the main sequence; the main sequence goes on
-    # without waiting until comm_join().
+    # that starts at a mark() of the main sequence (default: after everything enqueued so far); the
+    # main sequence goes on without waiting until comm_join().
     @contextlib.contextmanager
-    def comm_side(self):
+    def comm_side(self, after=None):
         if self._comm is None:
             self._comm = torch.cuda.Stream(self.device)
-        self._comm.wait_event(self.mark())
+        self._comm.wait_event(after if after is not None else self.mark())
         self._on_comm = True
         try:
             yield

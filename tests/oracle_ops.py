@@ -58,7 +58,7 @@ class OracleOps:
     def join_side(self):
         pass
 
-    def comm_side(self):
+    def comm_side(self, after=None):
         return contextlib.nullcontext()
 
     def comm_join(self):

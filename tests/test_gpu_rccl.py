@@ -52,9 +52,10 @@ def _worker(port, q):
         # the same batch on the communication stream, beside a kernel of the main sequence (split passes)
         with ops.ctx():
             scratch = torch.ones(1 << 20, dtype=torch.float64, device="cuda")
-        with ops.comm_side():
-            comm.run(batch)
+        ready = ops.mark()
         ops.zero_(scratch)
+        with ops.comm_side(ready):
+            comm.run(batch)
         ops.comm_join()
         with ops.ctx():
             inp = x[H:H + rows]
