@@ -157,7 +157,7 @@ class SlabMultigrid:
             self.bw.append(z(W.ny, W.ld))
             self.rw.append(z(W.ny, W.ld))
         # Several ranks, fused passes: a pass that follows a halo exchange is cut into the rows that depend
-        # on owned rows only -- launched at once, beside the exchange, which runs on a stream of its own --
+        # on owned rows only -- launched first; the exchange runs beside them on a stream of its own --
         # and the few rows at both slab ends, launched once the halo rows have arrived.  Done on levels
         # with at least overlap_min_rows rows per rank (None: never); on smaller ones the two extra launches
         # cost more than the exchange they hide.
