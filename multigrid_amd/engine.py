@@ -367,9 +367,7 @@ class SlabMultigrid:
         # The cuts are even rows (relative to the even halo depth): fine centres of coarse rows, so the
         # coarse rows of a fused restriction split with them.
         self.split_passes += 1
-        H, R = L.halo, L.rows
-        m = D + 2 + (D & 1)
-        a, e = H + m, H + R - m
+        a, e = self._cut(L, D)
         ready = self.ops.mark()         # the rows to be sent are final here
         launch(a, e)                    # enqueued first: the GPU has work while the host sets the exchange up
         with self.ops.comm_side(ready):
@@ -377,6 +375,14 @@ class SlabMultigrid:
         self.ops.comm_join()
         launch(L.t0, a)
         launch(e, L.t1)
+
+    @staticmethod
+    def _cut(L, D):
+        """Local rows (a, e) between which a pass of depth D on slab level L depends on owned rows only: the
+        stencil reaches D rows up and down, the prolongation one coarse row further; a and e are even
+        relative to the (even) halo depth."""
+        m = D + 2 + (D & 1)
+        return L.halo + m, L.halo + L.rows - m
 
     @staticmethod
     def _coarse_rows(Lc, H, j0, j1):

@@ -302,3 +302,31 @@ def test_choose_n_dist_weighs_rounds_against_the_all_gather():
     assert choose_n_dist(65, 65, 2, 4, 8) == 1             # slabs of 16 rows: the second level would hold fewer than the halo
     # free exchanges and a slow gather: distribute every level whose slabs are tall enough
     assert choose_n_dist(2 ** 15 + 1, 2 ** 15 + 1, 8, 2, 12, t_round=0.0, gather_bw=1e6) == 8
+
+
+def test_cut_passes_partition_rows_and_stay_clear_of_the_halo():
+    """The arithmetic of SlabMultigrid._pass at the benchmark's sizes (which no CPU run reaches): the three
+    launches of a cut pass partition the updated rows, their coarse rows partition the coarse level's, every
+    coarse row's fine centre lies in its own launch, and the interior launch reads owned rows only -- of the
+    fine arrays (D rows up and down) and of the coarse correction (the rows the prolongation touches)."""
+    for world, n_para, n_dist in ((2, 10, 5), (4, 10, 6), (8, 11, 6), (8, 8, 8)):
+        gny, gnx = world * 2 ** 15 + 1, 2 ** 15 + 1
+        for rank in range(world):
+            plan = make_plan(gny, gnx, n_para, world, rank, 1.0, halo=12, n_dist=n_dist)
+            H = plan.halo
+            for l in range(n_dist):
+                L, Lc = plan.levels[l], plan.levels[l + 1]
+                for D in (3, 5, 6, 8, 9, 10):
+                    if L.rows < 4 * (D + 4):
+                        continue
+                    a, e = SlabMultigrid._cut(L, D)
+                    parts = [(L.t0, a), (a, e), (e, L.t1)]
+                    assert L.t0 < a < e < L.t1 and (a - H) % 2 == 0 and (e - H) % 2 == 0
+                    # interior: fine rows read are owned and are not the rows next to the halo
+                    assert a - D > L.own0 and e + D - 1 < H + L.rows - 1
+                    # ... and so are the coarse rows under them: fine row t reads coarse rows (t+H)>>1 and +1
+                    assert ((a - D) + H) >> 1 >= H and (((e + D - 1) + H) >> 1) + 1 <= H + Lc.rows - 1
+                    T = [SlabMultigrid._coarse_rows(Lc, H, j0, j1) for j0, j1 in parts]
+                    assert T[0][0] == Lc.t0 and T[2][1] == Lc.t1 and T[0][1] == T[1][0] and T[1][1] == T[2][0]
+                    for (j0, j1), (T0, T1) in zip(parts, T):
+                        assert T0 < T1 and j0 <= 2 * T0 - H and 2 * (T1 - 1) - H < j1
