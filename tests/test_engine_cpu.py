@@ -284,6 +284,10 @@ def test_choose_n_para_keeps_the_whole_domain_level_in_lds():
             W0 = make_plan(gny, gnx, n_para - 1, world, 0).whole[0]
             assert not whole_level_fits_one_wave(W0.ny, W0.nx)
     assert choose_n_para(9, 9, 1, at_least=1) == 1
+    # bench.py's default: from n - 4 levels up (the reference's own proportion, a 33 x 33 whole-domain level)
+    for world, want in ((1, 10), (2, 10), (4, 10), (8, 11)):
+        assert choose_n_para(world * 2 ** 15 + 1, 2 ** 15 + 1, world, at_least=10) == want
+    assert choose_n_para(2 ** 15 + 1, 2 ** 15 + 1, 8, at_least=10) == 10  # strong scaling: 4096 rows per rank
 
 
 def test_choose_n_dist_weighs_rounds_against_the_all_gather():
