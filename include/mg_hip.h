@@ -251,7 +251,7 @@ int mg_graph_destroy(void *graph_exec);
  *                                                   bounds (ignored with FIX_COARSE_ASCENT)
  *                      MG_SOLVER_TUNE_PLACEMENT     create samples where in device memory the finest
  *                                                   level's arrays stream fastest (grids of >= 1 GiB
- *                                                   per array; a few seconds; results unchanged)
+ *                                                   per array; up to half a minute; results unchanged)
  *   mg_solver_set      "jacobi_omega" (0 < w <= 1, 1 = the reference's sweep), "max_cycles"
  *                      (default 100, :270), "recompute_min_nx" / "recompute_min_blocks" (size from
  *                      which a coarse level recomputes its pre-smoothing instead of storing it)

@@ -30,6 +30,7 @@ What differs from the reference is where the data lives and how it is cut:
 The engine is written against an ``ops`` object (multigrid_amd.ops.HipOps: the HIP kernels behind
 the C ABI) and a torch.distributed process group for the exchanges.
 """
+import time
 import warnings
 
 import torch
@@ -128,8 +129,11 @@ class SlabMultigrid:
         # the finest level's arrays first: x (two, ping-pong), b, r
         self.placement_gib = None  # GiB skipped in front of them (None: placement not tuned)
         fin = None
+        self.placement_seconds = 0.0
         if tune_placement and batch is None and getattr(ops, "supports_placement", False) and self.fused:
+            t0 = time.perf_counter()
             fin = self._place_finest(verbose=tune_placement == "verbose")
+            self.placement_seconds = time.perf_counter() - t0
         if fin is None:
             fin = [z(LV[0].ny, LV[0].ld) for _ in range(4)]
         self._xa = [fin[0]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
