@@ -313,8 +313,9 @@ def test_cut_passes_partition_rows_and_stay_clear_of_the_halo():
     launches of a cut pass partition the updated rows, their coarse rows partition the coarse level's, every
     coarse row's fine centre lies in its own launch, and the interior launch reads owned rows only -- of the
     fine arrays (D rows up and down) and of the coarse correction (the rows the prolongation touches)."""
-    for world, n_para, n_dist in ((2, 10, 5), (4, 10, 6), (8, 11, 6), (8, 8, 8)):
-        gny, gnx = world * 2 ** 15 + 1, 2 ** 15 + 1
+    # weak scaling (32768 rows per rank) and, last, strong scaling (32768 rows in all)
+    for world, n_para, n_dist, rows in ((2, 10, 5, None), (4, 10, 6, None), (8, 11, 6, None), (8, 8, 8, None), (8, 10, 4, 2 ** 15)):
+        gny, gnx = (rows or world * 2 ** 15) + 1, 2 ** 15 + 1
         for rank in range(world):
             plan = make_plan(gny, gnx, n_para, world, rank, 1.0, halo=12, n_dist=n_dist)
             H = plan.halo

@@ -142,3 +142,82 @@ def test_batch_of_1024_problems_equals_oracle_on_sampled_problems():
     assert per.shape == (B,) and float(per.max()) == errs[-1]
     assert float(per[517]) == float(r[517].abs().max())
     eng.close()
+
+
+def _two_rank_worker(rank, world, port, n, n_para, cycles, q):
+    import torch
+    import torch.distributed as dist
+    import bench
+    from multigrid_amd.engine import SlabMultigrid
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gnx = 2 ** (n + 1) + 1
+        eng = SlabMultigrid(world * 2 ** (n + 1) + 1, gnx, n_para, 20.0 / 2 ** (n + 1), 0.0, world=world, rank=rank,
+                            eager_dead_levels=True)
+        bench.fill_rhs(eng, torch, n, rank)
+        eng.presmooth()
+        errs = eng.cycles(cycles)
+        a, e = eng.owned_rows()
+        x = eng.local_rows(eng.x0)
+        picks = [0, 1, 7, 8, 9, 13, 14, 15, 16, 17, 100, (e - a) // 2, e - a - 18, e - a - 17, e - a - 16, e - a - 15, e - a - 9,
+                 e - a - 8, e - a - 2, e - a - 1]
+        q.put((rank, errs, eng.n_dist, eng.split_passes, picks, x[picks].cpu().numpy(),
+               eng.local_rows(eng.r0)[picks].cpu().numpy()))
+        dist.barrier()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_at_the_benchmark_slab_size_equal_one_rank():
+    """The multi-GPU bench's own slab size (32768 x 32769 per rank, five distributed levels, the four largest
+    with their passes cut around the halo exchange) on two ranks that share the GPU (gloo, messages staged
+    through the host): per-cycle norms equal those of one rank on the same 65537 x 32769 grid, and so do rows of
+    x and r at the slab ends, next to them and inside."""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+    import bench
+    from multigrid_amd.engine import SlabMultigrid
+    n, n_para, world, cycles = 14, 10, 2, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(rk, world, port, n, n_para, cycles, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    try:
+        for _ in range(world):
+            msg = q.get(timeout=140)
+            out[msg[0]] = msg[1:]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    one = SlabMultigrid(world * 2 ** (n + 1) + 1, 2 ** (n + 1) + 1, n_para, 20.0 / 2 ** (n + 1), 0.0, world=1, rank=0,
+                        eager_dead_levels=True)
+    bench.fill_rhs(one, torch, n, 0)
+    one.presmooth()
+    errs = one.cycles(cycles)
+    x, r = one.local_rows(one.x0), one.local_rows(one.r0)
+    R = 2 ** (n + 1)
+    for rank in range(world):
+        e_k, n_dist, cut, picks, xs, rs = out[rank]
+        assert e_k == errs
+        # cut: the opening pass, and per cycle the finest pass and the descent and ascent passes of levels 1-3
+        # (not the first descent pass of level 1: presmooth() ends with every halo exchanged)
+        assert n_dist == 5 and cut == 7 * cycles
+        rows = [rank * R + t for t in picks]
+        assert np.array_equal(xs, x[rows].cpu().numpy())
+        assert np.array_equal(rs, r[rows].cpu().numpy())
+    one.close()
