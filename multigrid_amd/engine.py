@@ -219,6 +219,9 @@ class SlabMultigrid:
             ops.stream.synchronize()
             t = ev[0].elapsed_time(ev[1]) / 3
             log.append((g, t))
+            if verbose:
+                print(f"placement {g:3d} GiB in front: {t:.3f} ms, arrays at GiB " +
+                      " ".join(f"{a.data_ptr() / 2 ** 30:.4f}" for a in arrs), flush=True)
             if best is None or t < best[0]:
                 best = (t, arrs, g)
             del arrs
