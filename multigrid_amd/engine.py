@@ -177,16 +177,53 @@ class SlabMultigrid:
         # store the finest residual in every cycle's pass instead of once at the end of solve()/cycles()
         self.store_residual_every_cycle = store_residual_every_cycle
 
+    def _sample_placements(self, cands, probe, label, verbose):
+        """Allocate the arrays probe.alloc() makes behind g GiB of other memory for every g of cands, time
+        probe.run on them, and return (arrays of the fastest placement, its g) -- the
+        arrays that were timed, not a second allocation -- or (None, None)."""
+        ops = self.ops
+        best, log = None, []
+        for g in cands:
+            sp = arrs = None
+            try:
+                sp = torch.empty(g << 27, dtype=torch.float64, device=ops.device) if g else None
+                arrs = probe.alloc()
+            except torch.OutOfMemoryError:  # someone else took the memory meanwhile: not a candidate
+                del sp, arrs
+                torch.cuda.empty_cache()
+                continue
+            del sp
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ops.begin()
+            for k in range(4):  # the first round is not timed
+                probe.run(arrs, k)
+                if k == 0:
+                    ev[0].record(ops.stream)
+            ev[1].record(ops.stream)
+            ops.stream.synchronize()
+            t = ev[0].elapsed_time(ev[1]) / 3
+            log.append((g, t))
+            if verbose:
+                print(f"placement of {label}, {g:3d} GiB in front: {t:.3f} ms, arrays at GiB " +
+                      " ".join(f"{a.data_ptr() / 2 ** 30:.4f}" for a in arrs), flush=True)
+            if best is None or t < best[0]:
+                best = (t, arrs, g)
+            del arrs
+            torch.cuda.empty_cache()
+        if verbose:
+            print(f"placement of {label}: ms by GiB in front:", " ".join(f"{g}:{t:.3f}" for g, t in log), flush=True)
+        return (best[1], best[2]) if best is not None else (None, None)
+
     def _place_finest(self, verbose=False):
         """Where in HBM the finest level's arrays land changes the rate of the pass that streams them by
-        several per cent (measured at 32769 x 32769: 5.8 to 6.4 ms for the same launch from one process
-        to the next on one device, and with the amount of memory allocated in front of the arrays; which
-        offsets are good differs from device to device).  So set-up samples placements: for 0, 10, ..
+        several per cent (measured at 32769 x 32769: 5.6 to 6.4 ms for the same launch from one process
+        to the next on one device, and with the amount of memory allocated in front of the arrays: it is
+        the physical memory behind the arrays that counts, not their addresses or their distance, and a
+        fresh process's first allocations are the slow ones).  So set-up samples placements: for 0, 10, ..
         120 GiB allocated in front (and released again), the four arrays are allocated and the finest
-        pass of the cycle is timed on them; the set with the fastest pass is the one that is kept --
-        the arrays that were timed, not a second allocation of the same size.  None when the level is
-        small (< 1 GiB per array) or memory is short."""
-        ops, L, Lc = self.ops, self.lv[0], self.plan.levels[1]
+        pass of the cycle is timed on them; the set with the fastest pass is the one that is kept.
+        None when the level is small (< 1 GiB per array) or memory is short."""
+        eng, ops, L, Lc = self, self.ops, self.lv[0], self.plan.levels[1]
         nbytes = L.ny * L.ld * 8
         if nbytes < (1 << 30):
             return None
@@ -196,42 +233,22 @@ class SlabMultigrid:
         if len(cands) < 2:
             return None
         crs, cb, norm = ops.zeros(Lc.ny, self.lv[1].ld), ops.zeros(Lc.ny, Lc.ld), ops.norm_slots()
-        best, log = None, []
-        for g in cands:
-            sp = arrs = None
-            try:
-                sp = torch.empty(g << 27, dtype=torch.float64, device=ops.device) if g else None
-                arrs = [ops.zeros(L.ny, L.ld) for _ in range(4)]
-            except torch.OutOfMemoryError:  # someone else took the memory meanwhile: not a candidate
-                del sp, arrs
-                torch.cuda.empty_cache()
-                continue
-            del sp
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            ops.begin()
-            for k in range(4):  # the cycle's launch on the finest level; the first one is not timed
-                ops.smooth_fused(arrs[2], arrs[k & 1], arrs[1 - (k & 1)], None, crs, L.nx, self.lv[1].nx, L.t0, L.t1,
-                                 L.fix_lo, L.fix_hi, L.oj, self.N2, L.h, norm, cb, Lc.nx, Lc.t0, Lc.t1,
-                                 omega=self.jacobi_omega)
-                if k == 0:
-                    ev[0].record(ops.stream)
-            ev[1].record(ops.stream)
-            ops.stream.synchronize()
-            t = ev[0].elapsed_time(ev[1]) / 3
-            log.append((g, t))
-            if verbose:
-                print(f"placement {g:3d} GiB in front: {t:.3f} ms, arrays at GiB " +
-                      " ".join(f"{a.data_ptr() / 2 ** 30:.4f}" for a in arrs), flush=True)
-            if best is None or t < best[0]:
-                best = (t, arrs, g)
-            del arrs
-            torch.cuda.empty_cache()
-        if verbose:
-            print("placement: ms per finest pass by GiB in front:", " ".join(f"{g}:{t:.3f}" for g, t in log), flush=True)
-        if best is None:
-            return None
-        self.placement_gib = best[2]
-        return best[1]
+
+        class Probe:
+            @staticmethod
+            def alloc():
+                return [ops.zeros(L.ny, L.ld) for _ in range(4)]
+
+            @staticmethod
+            def run(arrs, k):  # the cycle's launch on the finest level
+                ops.smooth_fused(arrs[2], arrs[k & 1], arrs[1 - (k & 1)], None, crs, L.nx, eng.lv[1].nx, L.t0, L.t1,
+                                 L.fix_lo, L.fix_hi, L.oj, eng.N2, L.h, norm, cb, Lc.nx, Lc.t0, Lc.t1,
+                                 omega=eng.jacobi_omega)
+
+        arrs, g = self._sample_placements(cands, Probe, "the finest arrays", verbose)
+        if arrs is not None:
+            self.placement_gib = g
+        return arrs
 
     # ------------------------------------------------------------------ data access
     @property
