@@ -211,6 +211,21 @@ int mg_copy2d(double *dst, int64_t dld, const double *src, int64_t sld, int64_t 
  */
 int mg_block_exchange(double *v, int64_t m, int64_t ld, int64_t bstride, double *stage, void *stream);
 
+/*
+ * mg_block_exchange without a staging argument and without any allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate device memory or carry a workspace -- code under
+ * hipGraph capture, tight serving loops, harnesses that forbid hipMalloc.  The 8*m doubles of staging
+ * live in a device array built into the library (MG_BLOCK_EXCHANGE_STATIC_MAX_SIDE * 64 bytes = 2 MiB,
+ * held by every GPU the library runs on until the process ends); blocks with m above
+ * MG_BLOCK_EXCHANGE_STATIC_MAX_SIDE are rejected with an error.  The call makes no hipMalloc/hipFree;
+ * the first call on a device looks up that device's copy of the array (make it outside stream capture).
+ * All calls on one GPU share the array: two calls that overlap in time on one GPU (different
+ * streams or host threads) race; calls on one stream are ordered and safe.  Results equal
+ * mg_block_exchange bit for bit.
+ */
+#define MG_BLOCK_EXCHANGE_STATIC_MAX_SIDE 32768
+int mg_block_exchange_static(double *v, int64_t m, int64_t ld, int64_t bstride, void *stream);
+
 /* a[0:n] = 0.0 (the `x[:] = 0` of core/parallel_multigrid.py:276,291,295), as a memset node. */
 int mg_zero(double *a, int64_t n, void *stream);
 

@@ -14,6 +14,7 @@ FLAG_FINEST = 1
 SOR_LEXICOGRAPHIC = 0
 SOR_REDBLACK = 1
 SOR_LDS_DOUBLES = 20000
+BLOCK_EXCHANGE_STATIC_MAX_SIDE = 32768
 
 _lib = None
 
@@ -47,6 +48,7 @@ SIGNATURES = {
     "mg_sor": ([_p, _p, _p, _i, _i, _i, _d, _i, _n, _n, _i, _i, _p], _n),
     "mg_copy2d": ([_p, _i, _p, _i, _i, _i, _p], _n),
     "mg_block_exchange": ([_p, _i, _i, _i, _p, _p], _n),
+    "mg_block_exchange_static": ([_p, _i, _i, _i, _p], _n),
     "mg_zero": ([_p, _i, _p], _n),
     "mg_split": ([_p, _i, _i, _i, _p, _i, _i, _i, _p], _n),
     "mg_graph_begin": ([_p], _n),

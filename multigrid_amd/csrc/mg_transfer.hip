@@ -10,6 +10,8 @@
 //
 // Arithmetic follows the reference's expression order (see include/mg_hip.h); the file is
 // compiled with -ffp-contract=off.
+#include <atomic>
+
 #include "mg_common.h"
 
 // ------------------------------------------------------------------------------- restriction
@@ -269,6 +271,49 @@ extern "C" int mg_block_exchange(double *v, i64 m, i64 ld, i64 bstride, double *
                (long long)m, (long long)ld, (long long)bstride);
     hipLaunchKernelGGL(mg_block_exchange_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, m, ld, bstride, stage);
     MG_LAUNCH_CHECK("mg_block_exchange");
+    return 0;
+}
+
+// The same exchange for callers that cannot allocate or bring a staging buffer: the 8*m doubles of
+// staging live in a file-scope device array.  Every GPU holds its own copy of the array at its own
+// address; that address is looked up once per device (the array's name is a host-side stand-in, not
+// a device address, and is never passed to a kernel).
+#define MG_BLOCK_EXCHANGE_STATIC_DOUBLES (8 * MG_BLOCK_EXCHANGE_STATIC_MAX_SIDE)
+#define MG_MAX_DEVICES 64
+static __device__ __align__(256) double scratch[MG_BLOCK_EXCHANGE_STATIC_DOUBLES];
+static std::atomic<double *> g_scratch_ptr[MG_MAX_DEVICES];
+
+static int mg_static_stage(double **out)
+{
+    int dev = -1;
+    MG_HIP(hipGetDevice(&dev));
+    MG_REQUIRE(dev >= 0 && dev < MG_MAX_DEVICES, "mg_block_exchange_static: device %d not supported (at most %d devices)",
+               dev, MG_MAX_DEVICES);
+    double *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        // Two host threads may both get here: both obtain the same address, so the double store is harmless.
+        MG_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        MG_REQUIRE(p, "mg_block_exchange_static: the staging array has no address on device %d", dev);
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int mg_block_exchange_static(double *v, i64 m, i64 ld, i64 bstride, void *stream)
+{
+    MG_REQUIRE(v, "mg_block_exchange_static: null array");
+    MG_REQUIRE(m >= 4 && ld >= m && bstride >= m * ld, "mg_block_exchange_static: bad shape (side %lld, ld %lld, stride %lld)",
+               (long long)m, (long long)ld, (long long)bstride);
+    MG_REQUIRE(m <= MG_BLOCK_EXCHANGE_STATIC_MAX_SIDE,
+               "mg_block_exchange_static: block side %lld exceeds the built-in staging array (at most %d); "
+               "use mg_block_exchange with a caller-provided stage",
+               (long long)m, MG_BLOCK_EXCHANGE_STATIC_MAX_SIDE);
+    double *stage = nullptr;
+    if (int rc = mg_static_stage(&stage)) return rc;
+    // Nothing to clear: the kernel writes all 8*m staging values before it reads any of them.
+    hipLaunchKernelGGL(mg_block_exchange_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, m, ld, bstride, stage);
+    MG_LAUNCH_CHECK("mg_block_exchange_static");
     return 0;
 }
 
