@@ -24,7 +24,7 @@ How the reference is executed
   calling rank, and a wrapper around ``coarse`` notes ``max|r_sb[0]|`` when it is called
   for level 0 (:273, i.e. right after the halo exchange of ``r``).
 
-Outputs (all small, committed): tests/golden/kernels.npz, layout.json, solve_*.npz.
+Outputs (all small, committed): tests/golden/kernels.npz, layout.json, global_*.npz, solve_*.npz.
 """
 import json
 import os
@@ -421,6 +421,102 @@ def gen_layout():
     print("layout.json:", len(layout), "cases")
 
 
+# --------------------------------------------------------------------------- undecomposed runs
+
+
+def run_global(b0, n_para, h0, ncycles, x_init=None, fix_coarse_ascent=False):
+    """The schedule of Multigrid.solve() (core/parallel_multigrid.py:264-347) driven on ONE undecomposed grid
+    with the reference's own kernels (the imported numba_modules functions): offsets 0, no exchange, no
+    gather/split -- the restriction of the last Jacobi level lands in b_wl[0] directly and x_wl[0] is the
+    correction.  This is the schedule the GPU slab engine runs; the arithmetic is the reference's.
+    Level sizes follow __init__ (:182-219) generalised to rectangles: Jacobi levels ((ny-1)>>l)+1, then
+    whole-domain levels down to 2 cells per side."""
+    nm, _, _ = _load_reference()
+    ny0, nx0 = b0.shape
+    n1, n2 = 3, 6  # :255-256
+    shp = lambda l: (((ny0 - 1) >> l) + 1, ((nx0 - 1) >> l) + 1)
+    x = [np.zeros(shp(l)) for l in range(n_para)]
+    b = [np.zeros(shp(l)) for l in range(n_para)]
+    r = [np.zeros(shp(l)) for l in range(n_para)]
+    h = [_check_h(h0 * 2 ** l) for l in range(n_para)]
+    b[0][:] = b0
+    if x_init is not None:
+        x[0][:] = x_init
+    xw, bw, rw, hw = [], [], [], []
+    l = n_para
+    while ((ny0 - 1) >> l) >= 2 and ((nx0 - 1) >> l) >= 2 and ((ny0 - 1) >> l) << l == ny0 - 1 and ((nx0 - 1) >> l) << l == nx0 - 1:
+        xw.append(np.zeros(shp(l))), bw.append(np.zeros(shp(l))), rw.append(np.zeros(shp(l)))
+        hw.append(_check_h(h0 * 2 ** l))
+        l += 1
+    L = len(xw)
+
+    def smooth_parallel(bb, xx, hh, rr, iterations):  # :100-114 without the exchanges
+        x_temp = np.zeros_like(xx)
+        x_temp[:] = xx
+        for _ in range(iterations):
+            nm.smooth_sweep_jacobi(bb, xx, x_temp, hh)
+        nm.residual(rr, xx, bb, hh)
+
+    errs = []
+    smooth_parallel(b[0], x[0], h[0], r[0], 1)  # :264-266
+    for _ in range(ncycles):
+        for lv in range(n_para):  # :272-288
+            if lv > 0:
+                x[lv][:] = 0
+                smooth_parallel(b[lv], x[lv], h[lv], r[lv], n1)
+            nm.coarse(r[lv], b[lv + 1] if lv + 1 < n_para else bw[0], 0, 0)
+        xw[0][:] = 0  # :291-293
+        nm.smooth_altern(bw[0], xw[0], hw[0], rw[0], n1)
+        for i in range(1, L):  # :294-297
+            xw[i][:] = 0
+            nm.coarse(rw[i - 1], bw[i], 0, 0)
+            nm.smooth_altern(bw[i], xw[i], hw[i], rw[i], n1)
+        for i in range(2, L + (1 if fix_coarse_ascent else 0)):  # :302-304 (range(2, n - n_para + 1) = range(2, L))
+            nm.interpolate_add_to(xw[-i + 1], xw[-i], 0, 0)
+            nm.smooth_altern(bw[-i], xw[-i], hw[-i], rw[-i], n2)
+        for lv in range(n_para - 1, -1, -1):  # :307-333
+            nm.interpolate_add_to(xw[0] if lv == n_para - 1 else x[lv + 1], x[lv], 0, 0)
+            smooth_parallel(b[lv], x[lv], h[lv], r[lv], n2)
+        errs.append(float(np.amax(np.abs(r[0]))))  # :336
+    return {"x": x[0], "r": r[0], "errs": np.array(errs), "x_last": x[-1], "b_last": b[-1],
+            **{f"xw{i}": a for i, a in enumerate(xw)}, **{f"bw{i}": a for i, a in enumerate(bw)},
+            **{f"rw{i}": a for i, a in enumerate(rw)}}
+
+
+GLOBAL_CASES = [
+    # name, ny, nx, n_para, right-hand side, cycles, fix_coarse_ascent
+    ("t33_p1", 33, 33, 1, "test", 4, False),
+    ("t33_p3", 33, 33, 3, "test", 4, False),
+    ("m65_p2", 65, 65, 2, "main", 4, False),
+    ("t65_p4", 65, 65, 4, "test", 3, False),
+    ("r65x33_p2", 65, 33, 2, "random", 3, False),
+    ("r33x129_p3", 33, 129, 3, "random", 3, False),
+    ("t129_p3", 129, 129, 3, "test", 3, False),
+    ("m129_p3_fix", 129, 129, 3, "main", 3, True),
+    ("rx65_p3", 65, 65, 3, "random_x", 3, False),   # non-zero Dirichlet values and initial guess in x
+]
+
+
+def gen_global(case):
+    name, ny, nx, n_para, rhs, ncycles, fix = case
+    x_init = None
+    if rhs in ("test", "main"):
+        n = int(np.log2(nx - 1)) - 1
+        b0, h = (test_rhs if rhs == "test" else main_rhs)(n)
+        assert b0.shape == (ny, nx)
+    else:
+        rng = np.random.default_rng(len(name) * 7 + ny + nx)
+        b0, h = rng.standard_normal((ny, nx)), 0.37
+        if rhs == "random_x":
+            x_init = rng.standard_normal((ny, nx))
+    out = run_global(b0, n_para, h, ncycles, x_init, fix)
+    out.update({"b0": b0, "h": h, "n_para": n_para, "ncycles": ncycles, "fix": int(fix)})
+    if x_init is not None:
+        out["x_init"] = x_init
+    np.savez_compressed(os.path.join(OUT, f"global_{name}.npz"), **out)
+    return name, out["errs"].tolist()
+
+
 SOLVE_CASES = [
     # name, n, n_para, rhs, eps, nsolves, mutate(test.py:77-78), keep
     ("t_n4_p1", 4, 1, "test", 0.025, 10, True, "blocks"),   # test.py's ten warm-started solves
@@ -441,11 +537,15 @@ SOLVE_CASES = [
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["kernels", "layout", "solves"]
+    which = sys.argv[1:] or ["kernels", "layout", "global", "solves"]
     if "kernels" in which:
         gen_kernels()
     if "layout" in which:
         gen_layout()
+    if "global" in which:
+        with ProcessPoolExecutor(max_workers=6) as ex:
+            for r in ex.map(gen_global, GLOBAL_CASES):
+                print("global", *r, flush=True)
     if "solves" in which:
         names = [a for a in which if a.startswith("solve:")]
         cases = [c for c in SOLVE_CASES if not names or ("solve:" + c[0]) in names]

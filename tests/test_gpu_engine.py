@@ -160,20 +160,34 @@ def _global_rhs_from_blocks(g, nsolve_index):
     return out, h
 
 
-# (golden run, tolerance on the per-cycle max|r|).  The engine is bit-identical to the undecomposed
-# schedule; the reference's 4-block run deviates from that by its one-exchange-old corner halo cell
-# at the point where the blocks meet, which matters more the fewer cells a block has on its
-# coarsest Jacobi level (deep n_para on a small grid) and when the source sits on the junction.
-# For the two "m_" runs the source is a single Gaussian centred exactly on that junction: there the
-# reference's first cycles differ from the undecomposed schedule by tens of per cent (its four
-# copies of the centre point disagree with each other), the histories meet again within 2 % after
-# a few cycles, and the solutions agree to 1e-4; only the last cycle is compared for them.
-HISTORY_CASES = [("t_n8_p4", 1e-4), ("t_n7_p4", 1e-4), ("t_n6_p3", 1e-4), ("t_n6_p5", 5e-3), ("t_n5_p4", 1e-2),
-                 ("t_n5_p2", 1e-3), ("t_n4_p3", 1e-2), ("m_n5_p2", None), ("m_n6_p3", None)]
+# (golden run, tolerance on the per-cycle max|r|, first cycle from which the tolerance and the 5 % criterion on
+# the reduction per V-cycle are asserted; cycles count from 1).  The engine is bit-identical to the undecomposed
+# schedule; the reference's 4-block run deviates from that by its one-exchange-old corner halo cells at the point
+# where the four blocks meet (the diagonal neighbour's cell reaches a block only with the second exchange after
+# it changed: weight 1/16 in the restriction, 1/4 in the prolongation, of one cell per level), which matters more
+# the fewer cells a block has on its coarsest Jacobi level (deep n_para on a small grid) and when the source sits
+# on the junction.
+# The "m_" runs are the reference module's own script (core/parallel_multigrid.py:351-415): a single Gaussian
+# centred exactly on that junction, where the residual has its maximum.  There the reference's first cycles are
+# dominated by the artefact -- its own per-rank errors (which include the stale halo copies) read 26.6, 20.5, 1.6
+# at n = 5 while the residual on the block interiors is 2.2, 0.16, 0.10 -- and the undecomposed schedule differs:
+#   max|r| after cycles 1, 2, 3 relative to the reference's interior max|r|
+#       m_n5_p2: -10 %, +116 %, +36 %     m_n6_p3: -14 %, +27 %, +30 %     m_n8_p4: -22 %, +51 %, +23 %
+#   reduction of cycles 2, 3, 4 relative to the reference's
+#       m_n5_p2: +142 %, -37 %, -23 %     m_n6_p3: +47 %, +2.5 %, -20 %    m_n8_p4: +93 %, -19 %, -14 %
+# From cycle 4 on max|r| is within 6 %, from cycle 5 on within 1.6 % and falling (0.1 % at the last cycle of
+# m_n8_p4); the reduction of cycle 5 is within 4.4 % and that of every later cycle within 0.4 %.  So the 5 %
+# criterion on the reduction per V-cycle holds from cycle 5 on and is asserted from there; cycles 2-4 of these
+# three runs are the ones the slab layout misses (the block-layout Multigrid reproduces them bit for bit,
+# tests/test_gpu_dropin.py).  Both runs reach the reference's tolerance in the same number of cycles.
+HISTORY_CASES = [("t_n8_p4", 1e-4, 1), ("t_n7_p4", 1e-4, 1), ("t_n6_p3", 1e-4, 1), ("t_n6_p5", 5e-3, 1), ("t_n5_p4", 1e-2, 1),
+                 ("t_n5_p2", 1e-3, 1), ("t_n4_p3", 1e-2, 1), ("m_n5_p2", 0.06, 4), ("m_n6_p3", 0.06, 4), ("m_n8_p4", 0.06, 4)]
+# the deviations of the first cycles listed above, as bounds: (max|r| of cycles 1-3, reduction of cycles 2-4)
+M_EARLY = {"m_n5_p2": (1.2, 1.5), "m_n6_p3": (0.35, 0.5), "m_n8_p4": (0.55, 1.0)}
 
 
-@pytest.mark.parametrize("name,tol", HISTORY_CASES, ids=lambda v: str(v))
-def test_history_matches_reference_runs(name, tol):
+@pytest.mark.parametrize("name,tol,first", HISTORY_CASES, ids=lambda v: str(v))
+def test_history_matches_reference_runs(name, tol, first):
     """Same right-hand sides as the reference's 4-rank runs (warm-started solves included).  The
     reference's own history is reproduced by the block oracle (bit-exact, test_oracle_golden.py);
     its per-rank error includes stale halo copies of the neighbours' residual, so the comparison
@@ -198,17 +212,54 @@ def test_history_matches_reference_runs(name, tol):
         eng.presmooth()
         hist = np.array(eng.cycles(it_ref))
         rel = np.abs(hist - blk.interior_hist) / blk.interior_hist
+        ratio = (hist[1:] / hist[:-1]) / (blk.interior_hist[1:] / blk.interior_hist[:-1])  # ratio[k]: reduction of cycle k + 2
         xg = np.zeros((N, N))
         oracle.gather_blocks(blk.x, xg)
         xrel = np.linalg.norm(_rows(eng, eng.x0) - xg) / np.linalg.norm(xg)
-        if tol is None:
-            assert rel[-1] < 0.02 and xrel < 1e-3, (s, rel, xrel)
-            continue
-        assert rel.max() < tol, (s, rel)
-        assert xrel < max(tol, 1e-4) * 0.1, (s, xrel)
-        # reduction per V-cycle: the 5 % criterion, met with a wide margin
-        ratio = (hist[1:] / hist[:-1]) / (blk.interior_hist[1:] / blk.interior_hist[:-1])
-        assert np.all(np.abs(ratio - 1) < 0.05)
+        # a warm-started solve of an "m_" run starts from the x of the first one: all of its cycles count as late
+        f = first if s == 0 else 1
+        assert rel[f - 1 :].max() < tol, (s, rel)
+        assert rel[-1] < min(tol, 0.025), (s, rel)
+        # reduction per V-cycle: the 5 % criterion
+        assert np.all(np.abs(ratio[max(f - 1, 0) :] - 1) < 0.05), (s, ratio)
+        assert np.all(np.abs(ratio[f + 1 :] - 1) < 0.005), (s, ratio)
+        if name in M_EARLY:
+            assert xrel < 1e-3, (s, xrel)
+            if s == 0:  # the documented misses of the first cycles stay what the table above says
+                assert rel[: f - 1].max() < M_EARLY[name][0] and np.abs(ratio[: f - 1] - 1).max() < M_EARLY[name][1], (rel, ratio)
+                # both schedules reach the tolerance of the run in the same cycle
+                assert (hist > float(g["eps"])).sum() == (blk.interior_hist > float(g["eps"])).sum()
+        else:
+            assert xrel < max(tol, 1e-4) * 0.1, (s, xrel)
+
+
+GLOBAL_RUNS = sorted(glob.glob(os.path.join(GOLDEN, "global_*.npz")))
+
+
+@pytest.mark.parametrize("path", GLOBAL_RUNS, ids=lambda p: os.path.basename(p)[7:-4])
+@pytest.mark.parametrize("graph,recompute", [(True, True), (False, False)])
+def test_engine_equals_reference_kernels_on_the_undecomposed_grid(path, graph, recompute):
+    """The engine against runs of the reference's own kernels (imported from the reference checkout when the
+    fixtures were made, oracle/gen_golden.py: run_global) driven through the schedule of
+    core/parallel_multigrid.py:264-347 on the undecomposed grid: per-cycle max|r|, x, r and the whole-domain
+    arrays, bit for bit -- no oracle in between."""
+    import torch
+    g = np.load(path)
+    b0 = g["b0"]
+    gny, gnx = b0.shape
+    fix = bool(int(g["fix"]))
+    eng = _make(gny, gnx, int(g["n_para"]), float(g["h"]), 0.0, b0, use_graph=graph, fix_coarse_ascent=fix,
+                recompute_presmoothing=recompute, recompute_min_nx=0, recompute_min_blocks=0, eager_dead_levels=True)
+    if "x_init" in g:
+        eng.set_x_rows(torch.from_numpy(g["x_init"]).cuda())
+    eng.presmooth()
+    assert eng.cycles(int(g["ncycles"])) == g["errs"].tolist()
+    assert np.array_equal(_rows(eng, eng.x0), g["x"])
+    assert np.array_equal(_rows(eng, eng.r0), g["r"])
+    eng.ops.synchronize()
+    for k, W in enumerate(eng.plan.whole):
+        assert np.array_equal(eng.xw[k].cpu().numpy()[:, : W.nx], g[f"xw{k}"]), k
+    eng.close()
 
 
 def test_solve_counts_cycles_like_the_reference():

@@ -8,8 +8,8 @@ largest grid is covered through properties that do not need the oracle:
     norm equals its max-norm;
   * scaling the right-hand side by a power of two scales the solution by exactly that factor
     (every operation of the cycle is linear and a power-of-two factor commutes with rounding).
-One size down (16385^2) the engine is compared with
-the oracle itself, bit for bit."""
+The engine is also compared with the oracle itself, bit for bit, at 4097^2, at 16385^2 and (where the host has the
+memory for the oracle's arrays) at 32769^2 with the benchmark's own level layout."""
 import os
 import sys
 
@@ -98,6 +98,69 @@ def test_engine_equals_oracle_at_16385():
     assert errs == ref.err_hist.tolist()
     assert np.array_equal(e.local_rows(e.x0).cpu().numpy(), ref.x)
     assert np.array_equal(e.local_rows(e.r0).cpu().numpy(), ref.r)
+    e.close()
+
+
+def _equal_rows(dev_rows, host, chunk=2048):
+    """dev_rows (a device view) == host (numpy), compared in row chunks so that no second full-size host copy exists."""
+    for a in range(0, host.shape[0], chunk):
+        if not np.array_equal(dev_rows[a : a + chunk].cpu().numpy(), host[a : a + chunk]):
+            return False
+    return True
+
+
+@pytest.mark.parametrize("graph,recompute", [(True, None), (True, True), (True, False), (False, True)],
+                         ids=["graph-default", "graph-recompute", "graph-stored", "eager-recompute"])
+def test_engine_equals_oracle_at_4097(graph, recompute):
+    """The 4096^2 configuration (n = 11, seven Jacobi levels, 33 x 33 first whole-domain level) against the oracle,
+    bit for bit: the captured cycle with the default choice of levels with recomputed pre-smoothing, with the
+    recompute scheme forced on every level, with it off, and launched eagerly."""
+    n, n_para = 11, 7
+    kw = {}
+    if recompute is not None:
+        kw = dict(recompute_presmoothing=recompute, recompute_min_nx=0, recompute_min_blocks=0)
+    e = _engine(n, n_para, eager_dead_levels=True, use_graph=graph, **kw)
+    N = e.plan.gnx
+    assert N == 4097 and e.plan.whole[0].nx == 33
+    ref = oracle.GlobalSolver(N, N, n_para, 20.0 / 2 ** (n + 1), 0.0)
+    ref.b[:] = e.local_rows(e.b0).cpu().numpy()
+    ref.solve(ncycles=2)
+    e.presmooth()
+    errs = e.cycles(2)
+    assert errs == ref.err_hist.tolist()
+    assert np.array_equal(e.local_rows(e.x0).cpu().numpy(), ref.x)
+    assert np.array_equal(e.local_rows(e.r0).cpu().numpy(), ref.r)
+    e.ops.synchronize()
+    for k, W in enumerate(e.plan.whole):
+        assert np.array_equal(e.xw[k].cpu().numpy()[:, : W.nx], ref.array("xw", k))
+    e.close()
+
+
+def test_engine_equals_oracle_at_32769():
+    """The benchmark's own workload (32769 x 32769, ten Jacobi levels, dead whole-domain levels computed every
+    cycle, one hipGraph per cycle) against the oracle, bit for bit: two cycles' max|r|, all of x and all of r.
+    The oracle holds 43 GB of level arrays on the host and needs a few seconds per cycle."""
+    import psutil
+    need = 70 << 30
+    if psutil.virtual_memory().available < need:
+        pytest.skip(f"the CPU oracle needs about 45 GB of host memory at this size; {psutil.virtual_memory().available >> 30} GiB available")
+    n, n_para = 14, 10
+    e = _engine(n, n_para, eager_dead_levels=True)
+    N = e.plan.gnx
+    assert N == 32769 and e.plan.whole[0].nx == 33
+    ref = oracle.GlobalSolver(N, N, n_para, 20.0 / 2 ** (n + 1), 0.0)
+    brows = e.local_rows(e.b0)
+    for a in range(0, N, 2048):
+        ref.b[a : a + 2048] = brows[a : a + 2048].cpu().numpy()
+    ref.solve(ncycles=2)
+    e.presmooth()
+    errs = e.cycles(2)
+    assert errs == ref.err_hist.tolist()
+    assert _equal_rows(e.local_rows(e.x0), ref.x)
+    assert _equal_rows(e.local_rows(e.r0), ref.r)
+    e.ops.synchronize()
+    for k, W in enumerate(e.plan.whole):
+        assert np.array_equal(e.xw[k].cpu().numpy()[:, : W.nx], ref.array("xw", k))
     e.close()
 
 

@@ -143,3 +143,32 @@ def test_block_solver_matches_reference(path):
         for k in range(4):
             assert np.array_equal(s.x[k][::8, ::8], g[f"x{k}_s8"])
             assert np.array_equal(s.r[k][::8, ::8], g[f"r{k}_s8"])
+
+
+GLOBALS = sorted(glob.glob(os.path.join(GOLDEN, "global_*.npz")))
+
+
+@pytest.mark.parametrize("path", GLOBALS, ids=lambda p: os.path.basename(p)[7:-4])
+def test_global_solver_matches_reference_kernels_on_the_undecomposed_grid(path):
+    """GlobalSolver (the oracle of the GPU slab engine) against runs in which the reference's own imported
+    kernels were driven through the schedule of core/parallel_multigrid.py:264-347 on one undecomposed grid
+    (oracle/gen_golden.py: run_global): per-cycle max|r|, x, r and every whole-domain array, bit for bit."""
+    g = np.load(path)
+    b0 = g["b0"]
+    ny, nx = b0.shape
+    s = oracle.GlobalSolver(ny, nx, int(g["n_para"]), float(g["h"]), 0.0, fix_coarse_ascent=bool(int(g["fix"])))
+    s.b[:] = b0
+    if "x_init" in g:
+        s.x[:] = g["x_init"]
+    s.solve(ncycles=int(g["ncycles"]))
+    assert s.err_hist.tolist() == g["errs"].tolist()
+    assert np.array_equal(s.x, g["x"])
+    assert np.array_equal(s.r, g["r"])
+    last = int(g["n_para"]) - 1
+    assert np.array_equal(s.array("x", last), g["x_last"])
+    assert np.array_equal(s.array("b", last), g["b_last"])
+    assert len(GLOBALS) >= 9
+    for i in range(s.nwl):
+        for name in ("xw", "bw", "rw"):
+            assert np.array_equal(s.array(name, i), g[f"{name}{i}"]), (name, i)
+    assert f"xw{s.nwl}" not in g
