@@ -282,7 +282,7 @@ def main():
                 "n": n, "n_para": n_para, "grid": [gny, gnx], "batch": args.batch or None, "unknowns": unknowns,
                 "coarse_ordering": args.ordering, "jacobi_omega": args.jacobi_omega, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
                 "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph), "fused_passes": bool(eng.fused), "recompute_presmoothing": bool(eng.recompute_presmoothing and eng.fused),
-                "placement_spacer_gib": eng.placement_gib, "placement_sampling_seconds": round(eng.placement_seconds, 2),
+                "placement": eng.placement, "placement_sampling_seconds": round(eng.placement_seconds, 2),
                 "halo_rows": eng.plan.halo, "distributed_levels": eng.n_dist if world > 1 else None,
                 "exchange_overlap": ({"min_rows_per_rank": eng.overlap_min_rows, "passes_cut": eng.split_passes,
                                       "rounds_per_cycle": eng.rounds_per_cycle()} if world > 1 else None),

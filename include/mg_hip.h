@@ -27,10 +27,10 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 4
+#define MG_ABI_VERSION 5
 
 /* flags for the stencil entry points */
-#define MG_FLAG_FINEST 1 /* launch the instantiation named "...finest..." (profiler attribution only) */
+#define MG_FLAG_FINEST 1 /* marks the launches of the finest level; ignored (large outputs get an instantiation of their own, see "stream_min_mib") */
 
 /* number of 8-byte slots a max-norm accumulator needs (see mg_residual) */
 #define MG_NORM_SLOTS 64
@@ -46,6 +46,9 @@ const char *mg_last_error(void);
  *   "fused_waves" 1 | 2 | 4  column strips (waves) per workgroup of the fused passes
  *   "fused_min_rows" 4..128  shortest tile (rows) the fused passes choose on levels too small to fill the chip
  *   "fused_min_blocks" n     ... tiles are halved while a launch has fewer workgroups than this
+ *   "stream_min_mib"  n      arrays of at least n MiB are written with streaming (non-temporal) stores, which keeps
+ *                            them from displacing in L2 / the Infinity Cache the rows other tiles re-read (default 256;
+ *                            a value beyond every array size switches them off)
  *   "sor_single_wave" 0|1|2  mg_sor, lexicographic: barrier-free one-wave kernel never / where it is
  *                            faster (default) / wherever the grid fits */
 int mg_set_tuning(const char *key, int value);
@@ -264,14 +267,15 @@ int mg_graph_destroy(void *graph_exec);
  *                      MG_SOLVER_LAZY_DEAD_LEVELS   skip the whole-domain levels below the first,
  *                                                   which nothing reads under the reference's loop
  *                                                   bounds (ignored with FIX_COARSE_ASCENT)
- *                      MG_SOLVER_TUNE_PLACEMENT     create samples where in device memory the finest
- *                                                   level's arrays stream fastest (grids of >= 1 GiB
- *                                                   per array; up to half a minute; results unchanged)
+ *                      MG_SOLVER_TUNE_PLACEMENT     create picks the finest level's arrays among up to 24
+ *                                                   candidate allocations by how fast the finest pass runs
+ *                                                   when it writes into each (grids of >= 1 GiB per array;
+ *                                                   about half a second; results unchanged)
  *   mg_solver_set      "jacobi_omega" (0 < w <= 1, 1 = the reference's sweep), "max_cycles"
  *                      (default 100, :270), "recompute_min_nx" / "recompute_min_blocks" (size from
  *                      which a coarse level recomputes its pre-smoothing instead of storing it)
- *   mg_solver_placement  GiB of memory create put in front of the finest arrays under
- *                      MG_SOLVER_TUNE_PLACEMENT (-1: placement was not tuned)
+ *   mg_solver_placement  number of candidate arrays create timed under MG_SOLVER_TUNE_PLACEMENT
+ *                      (-1: placement was not tuned)
  *   mg_solver_upload   finest-level b (MG_SOLVER_B) or x (MG_SOLVER_X: initial guess and Dirichlet
  *                      boundary values) from a host or device array of gny rows, src_ld apart
  *   mg_solver_solve    solve() (:232-348): one sweep + residual, then V-cycles until max|r| <= eps,
@@ -295,7 +299,7 @@ enum { MG_SOLVER_X = 0, MG_SOLVER_B = 1, MG_SOLVER_R = 2, MG_SOLVER_XW = 3, MG_S
 int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0, int flags, mg_solver **out);
 int mg_solver_destroy(mg_solver *s);
 int mg_solver_set(mg_solver *s, const char *key, double value);
-int mg_solver_placement(mg_solver *s, int *gib);
+int mg_solver_placement(mg_solver *s, int *candidates);
 int mg_solver_upload(mg_solver *s, int which, const double *src, int64_t src_ld);
 int mg_solver_download(mg_solver *s, int which, int level, double *dst, int64_t dst_ld);
 int mg_solver_array(mg_solver *s, int which, int level, double **device_ptr, int64_t *ny, int64_t *nx, int64_t *ld);

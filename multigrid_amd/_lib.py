@@ -7,8 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmg_hip.so")
-ABI_VERSION = 4
+# MG_HIP_LIB: another build of the library (A/B experiments with tools/); the default is the one beside this file
+LIB_PATH = os.environ.get("MG_HIP_LIB") or os.path.join(_HERE, "libmg_hip.so")
+ABI_VERSION = 5
 NORM_SLOTS = 64
 FLAG_FINEST = 1
 SOR_LEXICOGRAPHIC = 0

@@ -1,4 +1,4 @@
-// Explicit instantiations of the fused pass (one slice of them per unit: they compile in parallel).
+// Explicit instantiations of the fused pass (split over several files so that they compile in parallel).
 #include "mg_fused_kernel.h"
 
-template int pick_mode<6, false>(const FusedArgs &, bool, bool, bool, bool, hipStream_t);
+template int pick_mode<4, false>(const FusedArgs &, bool, bool, bool, bool, hipStream_t);

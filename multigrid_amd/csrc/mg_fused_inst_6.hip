@@ -1,7 +1,5 @@
-// Explicit instantiations of the fused pass: the 9-stage passes (3 sweeps from zero + prolongation + 6 sweeps).
+// Explicit instantiations of the fused pass (split over several files so that they compile in parallel).
 #include "mg_fused_kernel.h"
 
-template int launch_fused<9, true, true, true, false, 1, 3, false>(FusedArgs, hipStream_t);
-template int launch_fused<9, true, true, false, false, 1, 3, false>(FusedArgs, hipStream_t);
-template int launch_fused<9, true, true, true, false, 1, 3, true>(FusedArgs, hipStream_t);
-template int launch_fused<9, true, true, false, false, 1, 3, true>(FusedArgs, hipStream_t);
+template int pick_mode<1, true>(const FusedArgs &, bool, bool, bool, bool, hipStream_t);
+template int pick_mode<3, true>(const FusedArgs &, bool, bool, bool, bool, hipStream_t);

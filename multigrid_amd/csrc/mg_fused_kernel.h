@@ -15,13 +15,14 @@ struct FusedArgs {
     i64 ny, nx, ld, cny, cnx, cld;
     i64 j0, j1;          // rows to produce
     i64 flo, fhi;        // rows <= flo and >= fhi are fixed (Dirichlet): passed through
-    int rpb, ncb, nrc, ntc, oj;
+    int rpb, ncb, nrc, ntc, oj, stagger;
     double h2, hh;
     double om; // damped Jacobi: x + om * (t - x), t the undamped value (DAMPED instantiations only)
     u64 *norm;
     double *cb;          // coarse right-hand side produced by the fused restriction (RESTRICT)
     i64 cbnx, cbld, T0, T1; // its columns, leading dimension, and the coarse rows to produce
     i64 nbatch, bstride, cstride, cbstride; // number of grids; elements between consecutive grids of a batch: fine arrays, crs, cb
+    int stream; // streaming (non-temporal) stores: set when the arrays written dwarf the caches
 };
 
 __device__ __forceinline__ double lane_bcast(double v, int src)
@@ -64,7 +65,9 @@ using int_c = std::integral_constant<int, N>;
 // sweep (x += P(c), then K sweeps).  PS > 0 goes with ZERO: PS sweeps from x = 0, += P(c), K - PS
 // more sweeps -- a coarse level's pre-smoothing recomputed in front of its post-smoothing, so that
 // the descent need not store x and the ascent need not read it.
-template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0, bool DAMPED = false>
+// ST: x, r and the coarse right-hand side are written with streaming stores (see store_pair); a template
+// parameter because the compiler folds a run-time choice between the two kinds of store into one plain store.
+template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0, bool DAMPED = false, bool ST = false>
 __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
 {
     FusedArgs a = a0; // blockIdx.y = grid of the batch
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
     extern __shared__ double bring[]; // BL: (waves per workgroup) x NG x 3 row slots of W doubles
     const int wpb = blockDim.x >> 6;
     int cb, rc;
-    mg_tile_of_block((int)blockIdx.x, a.ncb, a.nrc, cb, rc);
+    mg_tile_of_block((int)blockIdx.x, a.ncb, a.nrc, cb, rc, a.stagger);
     const int lane = threadIdx.x & 63;
     const int tile = cb * wpb + (threadIdx.x >> 6);
     const bool active = tile < a.ntc;
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                         double *orow = a.xout + (i64)row * ld;
 #pragma unroll
                         for (int g = 0; g < U; ++g)
-                            if (st[g]) *reinterpret_cast<double2 *>(orow + (unsigned)c0[g]) = make_double2(o[g][0], o[g][1]);
+                            if (st[g]) store_pair<ST>(orow + (unsigned)c0[g], o[g][0], o[g][1]);
                     }
                     if constexpr (s < D) {
 #pragma unroll
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                                 double *rrow = a.r + (i64)row * ld;
 #pragma unroll
                                 for (int g = 0; g < U; ++g) {
-                                    if (a.r && st[g]) *reinterpret_cast<double2 *>(rrow + (unsigned)c0[g]) = make_double2(rv[g][0], rv[g][1]);
+                                    if (a.r && st[g]) store_pair<ST>(rrow + (unsigned)c0[g], rv[g][0], rv[g][1]);
                                     // with one column pair per lane, lanes outside the owned columns are
                                     // dropped once, after the loop
                                     if ((U == 1 || st[g]) && (PL || ic[g][0])) {
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                                         double v = rw[A1][g][0] / 4 + (rw[A2][g][0] + rw[A0][g][0]) * 1 / 8;
                                         v += a_right + a_left;
                                         const int I = c0[g] >> 1;
-                                        if (st[g] && I >= 1 && I <= (int)a.cbnx - 2) a.cb[(i64)T * a.cbld + I] = v;
+                                        if (st[g] && I >= 1 && I <= (int)a.cbnx - 2) store_one<ST>(&a.cb[(i64)T * a.cbld + I], v);
                                     }
                                 }
                             }
@@ -550,6 +553,7 @@ extern int g_fused_unroll; // column pairs per lane of the shallow passes
 extern int g_fused_rows;   // rows per tile, 0 = automatic
 extern int g_fused_min_rows; // shortest tile the automatic choice goes down to on small levels
 extern int g_fused_min_blocks; // ... as long as the launch has fewer workgroups than this
+extern int g_xcd_stagger;    // column blocks by which consecutive XCD bands are shifted; -1 = an eighth of the width
 
 template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0, bool DAMPED = false>
 int launch_fused(FusedArgs a, hipStream_t st)
@@ -572,10 +576,19 @@ int launch_fused(FusedArgs a, hipStream_t st)
         while (rpb > g_fused_min_rows && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) * a.nbatch < g_fused_min_blocks) rpb >>= 1;
     }
     a.rpb = rpb;
+    a.stagger = g_xcd_stagger < 0 ? a.ncb / 8 : g_xcd_stagger;
     a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
-    hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U, PS, DAMPED>),
-                       dim3((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), dim3(64 * wpb),
-                       DK >= 5 ? (size_t)wpb * ((DK + 1) / 3 + 1) * 3 * W * sizeof(double) : 0, st, a);
+    const dim3 grid((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), block(64 * wpb);
+    const size_t lds = DK >= 5 ? (size_t)wpb * ((DK + 1) / 3 + 1) * 3 * W * sizeof(double) : 0;
+    bool launched = false;
+    if constexpr (U == 1) { // arrays that large are never run with two column pairs per lane
+        if (a.stream) {
+            hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U, PS, DAMPED, true>), grid, block, lds, st, a);
+            launched = true;
+        }
+    }
+    if (!launched)
+        hipLaunchKernelGGL((mg_fused_kernel<K, PROLONG, ZERO, RESID, RESTRICT, U, PS, DAMPED, false>), grid, block, lds, st, a);
     MG_LAUNCH_CHECK("mg_smooth_fused");
     return 0;
 }

@@ -56,7 +56,7 @@ struct mg_solver {
     bool r_stale;  // the finest residual array is older than x
     int it;
     bool diverged;
-    int placement_gib; // GiB in front of the finest arrays chosen by MG_SOLVER_TUNE_PLACEMENT, -1: not tuned
+    int placement_candidates; // candidate arrays timed by MG_SOLVER_TUNE_PLACEMENT, -1: placement not tuned
     std::vector<double> hist;
 };
 
@@ -257,58 +257,109 @@ int materialize_residual(mg_solver *s)
 
 int read_err(mg_solver *s, double *err) { return mg_norm_read((const uint64_t *)s->norm, err, s->stream); }
 
-// Where in HBM the finest level's four arrays land changes the rate of the pass that streams them by
-// several per cent (32769 x 32769: 5.6 to 6.4 ms for the same launch, from one process to the next
-// and with the amount of memory allocated in front of the arrays).  With MG_SOLVER_TUNE_PLACEMENT
-// create samples placements: for 0, 10, .. 120 GiB allocated in front and released again, the four
-// arrays are allocated and zeroed and the cycle's finest pass is timed on them; the set with the
-// fastest pass is kept (the arrays that were timed).  fin[] stays null when the level is small
-// (< 1 GiB per array), memory is short or anything fails: create then allocates as usual.
-void place_finest(mg_solver *s, double *fin[4])
+// The same launch of the finest pass takes 5.4 or 6.1 ms at 32769 x 32769 depending on which allocations it
+// WRITES: x and the coarse right-hand side; the arrays it only reads matter by 2-3 %.  What decides is the
+// combination of the two written allocations, fixed when they are made and not predictable from user space (in a
+// fresh process the first eleven 8-GiB allocations are slow as x beside a coarse right-hand side allocated before
+// them, all later ones fast; a coarse right-hand side allocated after the fast ones makes the pass slow again).
+// With MG_SOLVER_TUNE_PLACEMENT create measures: the coarse right-hand side is allocated first AND KEPT (*cb_out:
+// it becomes the next level's b), candidates of the finest array's size are allocated one by one, each is timed
+// as the output of the cycle's finest pass, and as soon as both kinds have been seen and four candidates are of
+// the fast kind those become fin[] = {xa, xb, b, r}, in the assignment whose pass is fastest; all zero.  fin[]
+// and *cb_out stay null when the level is small (< 1 GiB per array), memory is short or anything fails: create
+// then allocates as usual.
+void place_finest(mg_solver *s, double *fin[4], double **cb_out)
 {
+    const int KMAX = 24;
     const i64 ny = s->gny, nx = s->gnx, ld = pitch(nx), n = ny * ld;
     const size_t bytes = (size_t)n * sizeof(double);
     for (int k = 0; k < 4; ++k) fin[k] = nullptr;
+    *cb_out = nullptr;
     size_t free_b = 0, total_b = 0;
     if (bytes < ((size_t)1 << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    // room for the other levels (a third of the finest's four arrays, rounded up to two arrays) and a margin
+    const size_t reserve = 2 * bytes + ((size_t)8 << 30);
+    int kmax = free_b > reserve ? (int)((free_b - reserve) / bytes) : 0;
+    if (kmax > KMAX) kmax = KMAX;
+    if (kmax < 6) return;
     const i64 cny = ((ny - 1) >> 1) + 1, cnx = ((nx - 1) >> 1) + 1, cld = pitch(cnx); // the next level, Jacobi or whole-domain
     const size_t cbytes = (size_t)(cny * cld) * sizeof(double);
     double *crs = nullptr, *cb = nullptr;
     u64 *norm = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool ready = hipMalloc((void **)&crs, cbytes) == hipSuccess && hipMalloc((void **)&cb, cbytes) == hipSuccess &&
-                 hipMalloc((void **)&norm, MG_NORM_SLOTS * sizeof(u64)) == hipSuccess &&
-                 hipMemsetAsync(crs, 0, cbytes, s->stream) == hipSuccess && hipMemsetAsync(cb, 0, cbytes, s->stream) == hipSuccess &&
-                 hipMemsetAsync(norm, 0, MG_NORM_SLOTS * sizeof(u64), s->stream) == hipSuccess &&
-                 hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-    float best = 0;
-    for (int g = 0; ready && g <= 120; g += 10) {
-        // the set kept so far + the set on trial + the memory in front, and room for the other levels
-        if (((size_t)g << 30) + 10 * bytes + ((size_t)8 << 30) > free_b) break;
-        void *front = nullptr;
-        double *a[4] = {nullptr, nullptr, nullptr, nullptr};
-        bool ok = g == 0 || hipMalloc(&front, (size_t)g << 30) == hipSuccess;
-        for (int k = 0; k < 4 && ok; ++k)
-            ok = hipMalloc((void **)&a[k], bytes) == hipSuccess && hipMemsetAsync(a[k], 0, bytes, s->stream) == hipSuccess;
-        if (front) (void)hipFree(front);
-        float ms = 0;
-        for (int k = 0; k < 4 && ok; ++k) { // the launch of finest_pass; the first one is not timed
-            ok = !mg_smooth_fused_restrict(a[2], a[k & 1], a[1 - (k & 1)], nullptr, crs, ny, nx, ld, cny, cnx, cld, 1, ny - 1, 0,
-                                           ny - 1, 0, N2, s->h0, 1.0, (uint64_t *)norm, cb, cny, cnx, cld, 1, cny - 1, 1, 0, 0, 0,
-                                           s->stream);
-            if (k == 0) ok = ok && hipEventRecord(e0, s->stream) == hipSuccess;
+    bool ok = hipMalloc((void **)&cb, cbytes) == hipSuccess && hipMalloc((void **)&crs, cbytes) == hipSuccess &&
+              hipMalloc((void **)&norm, MG_NORM_SLOTS * sizeof(u64)) == hipSuccess &&
+              hipMemsetAsync(crs, 0, cbytes, s->stream) == hipSuccess && hipMemsetAsync(cb, 0, cbytes, s->stream) == hipSuccess &&
+              hipMemsetAsync(norm, 0, MG_NORM_SLOTS * sizeof(u64), s->stream) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    auto time_pass = [&](double *b, double *xin, double *xout, float *ms) { // the launch of finest_pass; the first one is not timed
+        bool good = true;
+        for (int rep = 0; rep < 3 && good; ++rep) {
+            good = !mg_smooth_fused_restrict(b, xin, xout, nullptr, crs, ny, nx, ld, cny, cnx, cld, 1, ny - 1, 0, ny - 1, 0, N2,
+                                             s->h0, 1.0, (uint64_t *)norm, cb, cny, cnx, cld, 1, cny - 1, 1, 0, 0, 0, s->stream);
+            if (rep == 0) good = good && hipEventRecord(e0, s->stream) == hipSuccess;
         }
-        ok = ok && hipEventRecord(e1, s->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
-        const bool keep = ok && (!fin[0] || ms < best);
-        for (int k = 0; k < 4; ++k) {
-            if (keep) std::swap(a[k], fin[k]);
-            if (a[k]) (void)hipFree(a[k]);
+        good = good && hipEventRecord(e1, s->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+               hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+        return good;
+    };
+    double *a[KMAX];
+    float ms[KMAX];
+    int na = 0, nt = 0; // candidates allocated / timed
+    float lo = 0;
+    while (ok && na < kmax) {
+        if (hipMalloc((void **)&a[na], bytes) != hipSuccess) { // someone else took the memory: choose among what there is
+            (void)hipGetLastError();
+            break;
         }
-        if (keep) best = ms, s->placement_gib = g;
-        if (!ok) (void)hipGetLastError(); // e.g. a refused allocation: not a candidate
+        ok = hipMemsetAsync(a[na++], 0, bytes, s->stream) == hipSuccess;
+        if (na < 3) continue;
+        for (; ok && nt < na; ++nt) ok = time_pass(a[nt == 0 ? 1 : 0], a[nt <= 1 ? 2 : 1], a[nt], &ms[nt]);
+        if (!ok) break;
+        float hi = ms[0];
+        lo = ms[0];
+        for (int k = 1; k < nt; ++k) lo = ms[k] < lo ? ms[k] : lo, hi = ms[k] > hi ? ms[k] : hi;
+        int fast = 0;
+        for (int k = 0; k < nt; ++k) fast += ms[k] <= 1.03f * lo;
+        if (hi > 1.06f * lo && fast >= 4) break; // both kinds have been seen (they are 10 % or more apart)
+    }
+    if (ok && nt >= 4) {
+        int order[KMAX];
+        for (int k = 0; k < nt; ++k) order[k] = k;
+        for (int i = 1; i < nt; ++i) // insertion sort by time
+            for (int j = i; j > 0 && ms[order[j]] < ms[order[j - 1]]; --j) std::swap(order[j], order[j - 1]);
+        // the cycle's own combination: x moves between two of the four, b is a third; where the kinds are mixed two
+        // candidates that are fast as outputs may still make a slow pair: try the other assignments then
+        const int combos[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}, {0, 3, 1}, {1, 3, 0}, {2, 3, 0}};
+        int best = 0;
+        float tbest = 0;
+        for (int c = 0; c < 6 && ok; ++c) {
+            double *xa = a[order[combos[c][0]]], *xb = a[order[combos[c][1]]], *bb = a[order[combos[c][2]]];
+            float t0 = 0, t1 = 0;
+            ok = time_pass(bb, xa, xb, &t0) && time_pass(bb, xb, xa, &t1);
+            if (c == 0 || t0 + t1 < tbest) best = c, tbest = t0 + t1;
+            if (t0 + t1 <= 2 * 1.02f * lo) break;
+        }
+        const int q3 = 6 - combos[best][0] - combos[best][1] - combos[best][2];
+        const int pick[4] = {order[combos[best][0]], order[combos[best][1]], order[combos[best][2]], order[q3]};
+        for (int q = 0; q < 4 && ok; ++q) { // xa, xb, b, r; the timed launches left values in them: back to zero
+            fin[q] = a[pick[q]];
+            a[pick[q]] = nullptr;
+            ok = hipMemsetAsync(fin[q], 0, bytes, s->stream) == hipSuccess;
+        }
+        ok = ok && hipMemsetAsync(cb, 0, cbytes, s->stream) == hipSuccess;
+        if (ok) s->placement_candidates = nt, *cb_out = cb, cb = nullptr;
     }
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int q = 0; q < 4; ++q) {
+            if (fin[q]) (void)hipFree(fin[q]);
+            fin[q] = nullptr;
+        }
+    }
+    for (int k = 0; k < na; ++k)
+        if (a[k]) (void)hipFree(a[k]);
     if (crs) (void)hipFree(crs);
     if (cb) (void)hipFree(cb);
     if (norm) (void)hipFree(norm);
@@ -344,7 +395,7 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
     s->omega = 1.0, s->max_cycles = 100; // :270
     s->recompute_min_nx = 1024, s->recompute_min_blocks = 1024;
     s->norm = nullptr, s->stream = s->side = nullptr, s->fork = s->join = nullptr;
-    s->cur0 = 0, s->r_stale = true, s->it = 0, s->diverged = false, s->placement_gib = -1;
+    s->cur0 = 0, s->r_stale = true, s->it = 0, s->diverged = false, s->placement_candidates = -1;
     for (int a = 0; a < 2; ++a) s->graphs[a][0] = s->graphs[a][1] = nullptr, s->graph_end_cur[a] = 0;
     int rc = 1;
     do {
@@ -358,10 +409,12 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
         }
         bool ok = true;
         double *fin[4] = {nullptr, nullptr, nullptr, nullptr};
+        double *cb1 = nullptr; // what the finest pass restricts into, when the placement selection made it
         if (flags & MG_SOLVER_TUNE_PLACEMENT) {
-            place_finest(s, fin);
+            place_finest(s, fin, &cb1);
             for (int k = 0; k < 4; ++k)
                 if (fin[k]) s->allocs.push_back(fin[k]);
+            if (cb1) s->allocs.push_back(cb1);
         }
         for (int l = 0; l < n_para && ok; ++l) {
             JLevel L;
@@ -371,7 +424,11 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
             if (l == 0 && fin[0]) { // placed (and left all zero) by place_finest
                 L.xa = fin[0], L.xb = fin[1], L.b = fin[2], L.r = fin[3];
             } else {
-                ok = !dev_alloc(s, &L.xa, L.ny * L.ld) && !dev_alloc(s, &L.xb, L.ny * L.ld) && !dev_alloc(s, &L.b, L.ny * L.ld);
+                ok = !dev_alloc(s, &L.xa, L.ny * L.ld) && !dev_alloc(s, &L.xb, L.ny * L.ld);
+                if (ok && l == 1 && cb1)
+                    L.b = cb1;
+                else
+                    ok = ok && !dev_alloc(s, &L.b, L.ny * L.ld);
                 if (ok && l == 0) ok = !dev_alloc(s, &L.r, L.ny * L.ld);
             }
             s->lv.push_back(L);
@@ -381,7 +438,11 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
             if (my < 2 || mx < 2 || (my << l) != gny - 1 || (mx << l) != gnx - 1) break;
             WLevel W;
             W.ny = my + 1, W.nx = mx + 1, W.ld = pitch(W.nx), W.h = h0 * (double)((i64)1 << l);
-            ok = !dev_alloc(s, &W.x, W.ny * W.ld) && !dev_alloc(s, &W.b, W.ny * W.ld) && !dev_alloc(s, &W.r, W.ny * W.ld);
+            ok = !dev_alloc(s, &W.x, W.ny * W.ld) && !dev_alloc(s, &W.r, W.ny * W.ld);
+            if (ok && l == 1 && cb1) // one Jacobi level: the finest pass restricts into the first whole-domain level
+                W.b = cb1;
+            else
+                ok = ok && !dev_alloc(s, &W.b, W.ny * W.ld);
             s->wl.push_back(W);
         }
         if (!ok) break;
@@ -415,11 +476,11 @@ extern "C" int mg_solver_destroy(mg_solver *s)
     return 0;
 }
 
-extern "C" int mg_solver_placement(mg_solver *s, int *gib)
+extern "C" int mg_solver_placement(mg_solver *s, int *candidates)
 {
     if (check_device(s, "mg_solver_placement")) return 1;
-    MG_REQUIRE(gib, "mg_solver_placement: null output");
-    *gib = s->placement_gib;
+    MG_REQUIRE(candidates, "mg_solver_placement: null output");
+    *candidates = s->placement_candidates;
     return 0;
 }
 

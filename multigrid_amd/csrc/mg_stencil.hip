@@ -19,10 +19,11 @@
 enum { OP_JACOBI = 0, OP_JACOBI_ZERO = 1, OP_RESID = 2, OP_RESID_NORM = 3, OP_LAPLACE = 4 };
 
 // V = doubles per memory access (2 = one aligned 16-byte access, 1 = scalar for unaligned arrays),
+// STREAM = the output is written with streaming stores (arrays that dwarf the caches),
 // U = accesses per lane and row.  Group k of a lane covers columns c0 + k*64*V .. +V-1, so each
 // wave-level load/store instruction touches 64*V consecutive doubles (1 KiB when V = 2) and the
 // wave's tile is 64*V*U columns wide.
-template <int OP, int V, int U, bool FINEST>
+template <int OP, int V, int U, bool STREAM>
 __global__ __launch_bounds__(256) void mg_stencil5_kernel(const double *__restrict__ b, const double *__restrict__ x,
                                                           double *__restrict__ out, i64 nx, i64 ld, i64 j0, i64 j1,
                                                           int rpb, int ncb, int nrc, int linear_map, double s,
@@ -65,14 +66,14 @@ __global__ __launch_bounds__(256) void mg_stencil5_kernel(const double *__restri
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             if (full[k]) {
-                stv<V>(orow + c0[k], o[k]);
+                stv_stream<V, STREAM>(orow + c0[k], o[k]);
             } else if (any[k]) {
                 double keep[V];
                 ldv<V>(keep, orow + c0[k]);
 #pragma unroll
                 for (int v = 0; v < V; ++v)
                     if (!(c0[k] + v >= 1 && c0[k] + v <= nx - 2)) o[k][v] = keep[v];
-                stv<V>(orow + c0[k], o[k]);
+                stv_stream<V, STREAM>(orow + c0[k], o[k]);
             }
             if constexpr (OP == OP_RESID_NORM) {
 #pragma unroll
@@ -224,10 +225,12 @@ static int g_vec_cap = 2;   // doubles per access: 1 or 2
 static int g_unroll = 1;    // accesses per lane and row: 1, 2 or 4
 static int g_rows = 0;      // rows per tile, 0 = automatic
 static int g_linear_map = 0;
+i64 g_stream_min_bytes = (i64)256 << 20; // the Infinity Cache's size: what is larger cannot stay cached anyway
 extern int g_sor_single_wave; // mg_sor.hip
 extern int g_fused_waves;     // mg_fused.hip
 extern int g_fused_min_rows;  // mg_fused.hip
 extern int g_fused_min_blocks; // mg_fused.hip
+extern int g_xcd_stagger;      // mg_fused.hip
 
 extern "C" int mg_set_tuning(const char *key, int value)
 {
@@ -252,6 +255,12 @@ extern "C" int mg_set_tuning(const char *key, int value)
     } else if (!strcmp(key, "fused_min_blocks")) {
         MG_REQUIRE(value >= 1 && value <= (1 << 20), "mg_set_tuning: fused_min_blocks must be 1..2^20");
         g_fused_min_blocks = value;
+    } else if (!strcmp(key, "xcd_stagger")) {
+        MG_REQUIRE(value >= -1 && value <= (1 << 20), "mg_set_tuning: xcd_stagger must be -1 (an eighth of the width) or >= 0");
+        g_xcd_stagger = value;
+    } else if (!strcmp(key, "stream_min_mib")) {
+        MG_REQUIRE(value >= 0, "mg_set_tuning: stream_min_mib must be >= 0");
+        g_stream_min_bytes = (i64)value << 20;
     } else if (!strcmp(key, "sor_single_wave")) {
         MG_REQUIRE(value >= 0 && value <= 2, "mg_set_tuning: sor_single_wave must be 0, 1 or 2");
         g_sor_single_wave = value;
@@ -276,7 +285,7 @@ static int rows_per_block(i64 nrows, int ncb, i64 nbatch)
 }
 
 template <int OP, int V, int U>
-static int launch_stencil(const double *b, const double *x, double *out, i64 nx, i64 ld, i64 j0, i64 j1, double s,
+static int launch_stencil(const double *b, const double *x, double *out, i64 ny, i64 nx, i64 ld, i64 j0, i64 j1, double s,
                           double om, i64 nbatch, i64 bstride, u64 *slots, int flags, hipStream_t st, const char *name)
 {
     const int bw = 256 * V * U;                        // columns per workgroup
@@ -284,7 +293,9 @@ static int launch_stencil(const double *b, const double *x, double *out, i64 nx,
     const int rpb = rows_per_block(j1 - j0, ncb, nbatch);
     const int nrc = (int)((j1 - j0 + rpb - 1) / rpb);
     dim3 grid((unsigned)(ncb * nrc), (unsigned)nbatch);
-    if (flags & MG_FLAG_FINEST)
+    // streaming stores for outputs that dwarf the caches (which also gives those launches a kernel name of their own)
+    (void)flags;
+    if (mg_streams(ny * ld * nbatch * (i64)sizeof(double)))
         hipLaunchKernelGGL((mg_stencil5_kernel<OP, V, U, true>), grid, dim3(256), 0, st, b, x, out, nx, ld, j0, j1,
                            rpb, ncb, nrc, g_linear_map, s, om, bstride, slots);
     else
@@ -343,7 +354,7 @@ extern "C" int mg_jacobi(const double *b, const double *x, double *x_out, i64 ny
     MG_REQUIRE(x != x_out, "mg_jacobi: x_out aliases x");
     if (j0 == j1) return 0;
     const int v = vec_width(ld, bstride, nbatch, b, x, x_out);
-    DISPATCH_VU(OP_JACOBI, b, x, x_out, nx, ld, j0, j1, h * h, omega, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
+    DISPATCH_VU(OP_JACOBI, b, x, x_out, ny, nx, ld, j0, j1, h * h, omega, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
                 "mg_jacobi");
 }
 
@@ -355,7 +366,7 @@ extern "C" int mg_jacobi_from_zero(const double *b, double *x_out, i64 ny, i64 n
     MG_REQUIRE(b && x_out, "mg_jacobi_from_zero: null array");
     if (j0 == j1) return 0;
     const int v = vec_width(ld, bstride, nbatch, b, x_out, nullptr);
-    DISPATCH_VU(OP_JACOBI_ZERO, b, nullptr, x_out, nx, ld, j0, j1, h * h, omega, nbatch, bstride, nullptr, flags,
+    DISPATCH_VU(OP_JACOBI_ZERO, b, nullptr, x_out, ny, nx, ld, j0, j1, h * h, omega, nbatch, bstride, nullptr, flags,
                 (hipStream_t)stream, "mg_jacobi_from_zero");
 }
 
@@ -369,9 +380,9 @@ extern "C" int mg_residual(double *r, const double *x, const double *b, i64 ny, 
     const int v = vec_width(ld, bstride, nbatch, b, x, r);
     const double hh = 1 / (h * h);
     if (norm_slots)
-        DISPATCH_VU(OP_RESID_NORM, b, x, r, nx, ld, j0, j1, hh, 1.0, nbatch, bstride, (u64 *)norm_slots, flags,
+        DISPATCH_VU(OP_RESID_NORM, b, x, r, ny, nx, ld, j0, j1, hh, 1.0, nbatch, bstride, (u64 *)norm_slots, flags,
                     (hipStream_t)stream, "mg_residual");
-    DISPATCH_VU(OP_RESID, b, x, r, nx, ld, j0, j1, hh, 1.0, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
+    DISPATCH_VU(OP_RESID, b, x, r, ny, nx, ld, j0, j1, hh, 1.0, nbatch, bstride, nullptr, flags, (hipStream_t)stream,
                 "mg_residual");
 }
 
@@ -380,7 +391,7 @@ extern "C" int mg_laplacian(const double *x, double *lplc, i64 ny, i64 nx, i64 l
     if (check_grid("mg_laplacian", ny, nx, ld, 1, ny - 1, 1, 0)) return 1;
     MG_REQUIRE(x && lplc && x != lplc, "mg_laplacian: null or aliased array");
     const int v = vec_width(ld, 0, 1, x, lplc, nullptr);
-    DISPATCH_VU(OP_LAPLACE, nullptr, x, lplc, nx, ld, 1, ny - 1, 1 / (h * h), 1.0, 1, 0, nullptr, 0, (hipStream_t)stream,
+    DISPATCH_VU(OP_LAPLACE, nullptr, x, lplc, ny, nx, ld, 1, ny - 1, 1 / (h * h), 1.0, 1, 0, nullptr, 0, (hipStream_t)stream,
                 "mg_laplacian");
 }
 

@@ -37,8 +37,8 @@ class NativeSolver:
             self.set("recompute_min_blocks", recompute_min_blocks)
 
     @property
-    def placement_gib(self):
-        """GiB of memory put in front of the finest arrays by tune_placement; None: placement not tuned."""
+    def placement_candidates(self):
+        """Number of candidate arrays tune_placement timed to pick the finest x arrays; None: placement not tuned."""
         g = C.c_int()
         check(self.L.mg_solver_placement(self._h, C.byref(g)))
         return None if g.value < 0 else g.value

@@ -169,15 +169,15 @@ def test_c_program_runs_the_reference_script():
 
 
 def test_tuned_placement_changes_nothing_but_where_the_arrays_lie():
-    """MG_SOLVER_TUNE_PLACEMENT: create samples placements of the finest arrays (grids of at least 1 GiB per
-    array) and keeps the arrays of the fastest one, zeroed; everything computed afterwards is the same."""
+    """MG_SOLVER_TUNE_PLACEMENT: create times candidate allocations as the output of the finest pass (grids of at
+    least 1 GiB per array) and keeps the fastest as the x arrays, zeroed; everything computed afterwards is the same."""
     from multigrid_amd.solver import NativeSolver
     gny, gnx, n_para = 16385, 8193, 8
     b = _rhs(gny, gnx, 2)
     out = []
     for tune in (True, False):
         s = NativeSolver(gny, gnx, n_para, 0.01, tune_placement=tune)
-        assert (s.placement_gib is not None) == tune
+        assert (s.placement_candidates is not None) == tune
         s.upload("b", b)
         s.presmooth()
         errs = s.cycles(2)
@@ -187,5 +187,5 @@ def test_tuned_placement_changes_nothing_but_where_the_arrays_lie():
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     # small grids are left alone
     s = NativeSolver(257, 257, 3, 0.3, tune_placement=True)
-    assert s.placement_gib is None
+    assert s.placement_candidates is None
     s.close()
