@@ -9,18 +9,28 @@ convergence value read back by the host) on a right-hand side that is already re
 
 Workload: the configuration BASELINE.json's metric is quoted on -- a 32769 x 32769 float64 grid
 (n = 14, ~1.07e9 unknowns, 46 GB of level arrays) per GPU.  With N > 1 ranks (one process per GPU,
-launched by torch.distributed.run) every rank keeps that slab and the global grid grows to
-(N * 32768 + 1) x 32769 rows x columns: weak scaling.  The halo rows of the distributed levels travel by
-RCCL send/recv; the levels with fewer than 256 rows per rank are all-gathered once per cycle and computed
-redundantly on every rank.
+launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py
+--gpus N`, before anything touches a GPU) every rank keeps that slab and the global grid grows to
+(N * 32768 + 1) x 32769 rows x columns: weak scaling.  The halo rows of the distributed levels travel by RCCL
+send/recv; how many of the Jacobi levels are cut into slabs is decided by a cost model of one cycle
+(levels.choose_n_dist: 5, 6, 6 at N = 2, 4, 8; `config.distributed_levels` reports it); the levels below are
+all-gathered once per cycle and computed redundantly on every rank.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the dominant kernel (the finest level's fused pass: prolongation, 6 Jacobi sweeps,
-                residual, max-norm and restriction in one launch): algorithmic bytes per launch / its
-                average duration, timed here with HIP events on the stream the kernel runs on, against
-                the 8 TB/s HBM peak; the plain Jacobi sweep (24 B per point) is reported beside it
-  cpu_baseline  the CPU oracle (C restatement of the reference algorithm, OpenMP over rows) timed
-                on this host's cores on a bounded sample (a smaller grid, a few V-cycles)
+  roofline      the dominant kernel (the finest level's fused pass: prolongation, 6 Jacobi sweeps, residual,
+                max-norm and restriction in one launch).  `achieved` = the bytes that launch itself must move
+                (28 B per point: it reads x, b and the coarse x, writes x and the coarse b, each once) / its
+                average duration, timed here with HIP events on the stream the kernel runs on; `frac` = that
+                over the 8 TB/s HBM peak.  `algorithmic_equivalent` prices the same launch by the bytes the
+                operations it performs would move one by one (196 B per point): a throughput equivalent, not
+                a bandwidth.  `traffic` = HBM bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE counters
+                (profiles/traffic.json, measured on tools/pmc_probe.py; printed only when the kernel sources
+                are the ones it was measured on).  The plain Jacobi sweep (24 B per point) is beside it.
+  cycle         the same two prices for the whole V-cycle
+  cpu_baseline  the CPU oracle (C restatement of the reference algorithm) timed on this host's cores on a
+                bounded sample: the undecomposed schedule with OpenMP row-parallel sweeps on all cores, and
+                the reference's own decomposition -- four 2 x 2 blocks, one thread per block, an exchange per
+                sweep -- at n = 8 .. 11 (`four_ranks_2x2`)
 """
 import argparse
 import json
@@ -62,6 +72,8 @@ def parse():
     ap.add_argument("--no-tune-placement", action="store_true",
                     help="allocate the level arrays where the allocator puts them instead of timing a few "
                          "placements of the finest level's arrays at set-up and keeping the fastest")
+    ap.add_argument("--no-untuned-leg", action="store_true",
+                    help="skip the few cycles on arrays without placement selection that are reported beside the result")
     ap.add_argument("--batch", type=int, default=0,
                     help="B > 0: B independent (2**(n+1)+1)^2 problems advance together on one GPU "
                          "(e.g. --batch 1024 --exp 7 --jacobi-levels 4); not the headline workload")
@@ -135,18 +147,29 @@ def cpu_baseline(args):
                   f"algorithm with OpenMP row-parallel sweeps, {dt:.1f} s",
         "ms_per_cycle": 1e3 * dt / cycles,
     }
-    # the same on 4 threads: the reference itself runs on exactly 4 MPI ranks
-    allthreads = oracle.num_threads()
-    try:
-        oracle.set_num_threads(4)
-        c4 = max(2, min(cycles, int(8.0 / max(t1 * allthreads / 4, 1e-3))))
+    # The reference's own decomposition: four blocks (2 x 2) with a duplicated centre line, one worker per block
+    # as its `mpiexec -n 4` (core/Makefile:7, test/Makefile:9), a halo exchange after every sweep.  n_para = n - 4
+    # keeps the 33 x 33 first whole-domain level of its own n = 8, n_para = 4 run.
+    legs = []
+    for nb in (8, 9, 10, 11):
+        bb, hb = test_rhs(nb)
+        blk = oracle.BlockSolver(nb, nb - 4, hb, 0.0, rank_parallel=True)
+        for k in range(4):
+            oracle.split(bb, blk.b[k], k)
+        blk.set_max_cycles(2)
+        blk.solve()  # first touch
+        cyc = {8: 60, 9: 40, 10: 16, 11: 6}[nb]
+        blk.set_max_cycles(cyc)
         t0 = time.perf_counter()
-        s.solve(ncycles=c4)
-        d4 = time.perf_counter() - t0
-        out["four_workers"] = {"value": unknowns * c4 / d4, "cores": 4, "ms_per_cycle": 1e3 * d4 / c4,
-                               "sample": f"{c4} V-cycles of the same run on 4 threads (the reference runs 4 MPI ranks), {d4:.1f} s"}
-    finally:
-        oracle.set_num_threads(allthreads)
+        blk.solve()
+        db = time.perf_counter() - t0
+        unk = (2 ** (nb + 1) - 1) ** 2
+        legs.append({"n": nb, "n_para": nb - 4, "grid": 2 ** (nb + 1) + 1, "cycles": blk.it, "ms_per_cycle": 1e3 * db / blk.it,
+                     "value": unk * blk.it / db})
+    out["four_ranks_2x2"] = {"unit": "unknowns*V-cycles/s", "cores": 4, "kind": "port",
+                             "sample": "oracle.BlockSolver (the reference's four 2x2 blocks, one thread per block, exchange "
+                                       "per sweep, test.py right-hand side) at n = 8..11, n_para = n - 4",
+                             "runs": legs}
     return out
 
 
@@ -170,7 +193,7 @@ def main():
             dist.init_process_group("gloo")
 
     from multigrid_amd.engine import SlabMultigrid
-    from multigrid_amd.levels import algorithmic_bytes_per_cycle
+    from multigrid_amd.levels import algorithmic_bytes_per_cycle, own_bytes_per_cycle
 
     from multigrid_amd.levels import choose_n_para
     n = args.n
@@ -183,14 +206,35 @@ def main():
         sys.exit(f"no admissible number of Jacobi levels for a {gny}x{gnx} grid on {world} ranks")
     args.n_para = n_para
     h = 20.0 / 2 ** (n + 1)
-    eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
-                        use_graph=not args.no_graph, fused=not args.no_fused,
-                        eager_dead_levels=not args.lazy_dead_levels, batch=args.batch or None,
-                        recompute_presmoothing=not args.no_recompute, jacobi_omega=args.jacobi_omega,
-                        tune_placement=not args.no_tune_placement)
+
+    def make_engine(tune):
+        e = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
+                          use_graph=not args.no_graph, fused=not args.no_fused,
+                          eager_dead_levels=not args.lazy_dead_levels, batch=args.batch or None,
+                          recompute_presmoothing=not args.no_recompute, jacobi_omega=args.jacobi_omega,
+                          tune_placement=tune)
+        fill_rhs(e, torch, n, rank)
+        torch.cuda.synchronize()
+        return e
+
+    # What the same cycle costs on arrays taken as the allocator hands them out (no placement selection): a few
+    # cycles on an engine of its own, built first -- as a process that does not select would build it -- and
+    # released again.  One rank only (a rehearsal, outside the timed region of the benchmark proper).
+    untuned_ms = None
+    if world == 1 and not args.no_tune_placement and not args.batch and not args.no_untuned_leg and not args.no_fused:
+        e0 = make_engine(False)
+        e0.presmooth()
+        e0.cycles(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.cycles(5)
+        torch.cuda.synchronize()
+        untuned_ms = 1e3 * (time.perf_counter() - t0) / 5
+        e0.close()
+        del e0
+        torch.cuda.empty_cache()
+    eng = make_engine(not args.no_tune_placement)
     nprob = args.batch or 1
-    fill_rhs(eng, torch, n, rank)
-    torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -232,8 +276,8 @@ def main():
         return ev0.elapsed_time(ev1) / iters
 
     sweep_ms = timed(lambda k: ops.jacobi(eng.b[0], xs[k & 1], xs[1 - (k & 1)], L0.nx, L0.t0, L0.t1, L0.h, True))
-    single = {"kernel": "mg_stencil5_kernel<0 (Jacobi), 2, 1, true (finest level)>", "avg_launch_ms": sweep_ms,
-              "algorithmic_bytes_per_launch": 24 * pts_launch, "achieved": 24 * pts_launch / (sweep_ms * 1e-3) / 1e9}
+    single = {"kernel": "mg_stencil5_kernel<0 (Jacobi), 2, 1, streaming stores when the array is >= 256 MiB>", "avg_launch_ms": sweep_ms,
+              "bytes_per_launch": 24 * pts_launch, "achieved": 24 * pts_launch / (sweep_ms * 1e-3) / 1e9}
     single["frac"] = single["achieved"] / HBM_PEAK_GBPS
     if eng.fused:
         # the correction and the restriction target as the cycle passes them: slab arrays of level 1, or, when
@@ -250,28 +294,45 @@ def main():
         pass_ms = timed(lambda k: ops.smooth_fused(eng.b[0], xs[k & 1], xs[1 - (k & 1)], None, crs, L0.nx, L1.nx,
                                                    L0.t0, L0.t1, L0.fix_lo, L0.fix_hi, L0.oj, 6, L0.h, eng.norm,
                                                    cb1, L1.nx, L1.t0, L1.t1, omega=args.jacobi_omega))
-        dom_name = (f"mg_fused_kernel<6, true, false, true, true, 1, 0, {'false' if args.jacobi_omega == 1.0 else 'true'}> "
-                    "(finest level: prolongation + 6 Jacobi sweeps + residual + max-norm + restriction)")
+        streams = L0.ny * L0.ld * 8 * (args.batch or 1) >= (256 << 20)  # the instantiation with streaming stores
+        dom_name = (f"mg_fused_kernel<6, true, false, true, true, 1, 0, {'false' if args.jacobi_omega == 1.0 else 'true'}, "
+                    f"{'true' if streams else 'false'}> (finest level: prolongation + 6 Jacobi sweeps + residual + max-norm + restriction)")
         dom_ms = pass_ms
         alg_bpp = 18 + 6 * 24 + 24 + 10  # per-operation compulsory bytes x the operations this launch performs
         own_bpp = 8 + 2 + 8 + 8 + 2      # what the pass itself must move: R x, R coarse x, R b, W x, W coarse b
         tkey = "fused_finest_bytes_per_launch"
     else:
         dom_name, dom_ms, alg_bpp, own_bpp, tkey = single["kernel"], sweep_ms, 24, 24, "jacobi_finest_bytes_per_launch"
+    own_bytes_launch = own_bpp * pts_launch
     alg_bytes_launch = alg_bpp * pts_launch
-    achieved = alg_bytes_launch / (dom_ms * 1e-3) / 1e9
+    achieved = own_bytes_launch / (dom_ms * 1e-3) / 1e9
 
     if rank == 0:
         unknowns = (gny - 2) * (gnx - 2) * nprob
         ms = 1e3 * dt / args.steps
-        traffic = None
+        # HBM bytes per launch of the dominant kernel from rocprofv3 counters: measured on tools/pmc_probe.py at
+        # 32769 x 32769 and kept in profiles/traffic.json with a digest of the kernel sources it was measured on
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and n == 14 and not args.batch:  # measured at 32769 x 32769
+        if n != 14 or args.batch or world != 1:
+            traffic_source = "not measured for this workload (profiles/traffic.json holds the 32769 x 32769 launches)"
+        elif not os.path.exists(tpath):
+            traffic_source = "profiles/traffic.json is missing"
+        else:
             try:
-                traffic = json.load(open(tpath)).get(tkey)
-            except Exception:
-                traffic = None
+                from multigrid_amd._lib import sources_digest
+                tj = json.load(open(tpath))
+                if tj.get("csrc_sha256") == sources_digest():
+                    traffic = tj.get(tkey)
+                    traffic_source = ("static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/pmc_probe.py, "
+                                      "same kernel sources, sha256 " + tj["csrc_sha256"][:12] + "); not collected in this run")
+                else:
+                    traffic_source = "profiles/traffic.json was measured on other kernel sources: not reported"
+            except Exception as e:
+                traffic_source = f"profiles/traffic.json unreadable: {e!r}"
         bcyc = algorithmic_bytes_per_cycle(eng.plan) * nprob
+        recomputed = [l for l in range(1, n_para) if eng.fused and eng._recomputed(l)]
+        own_cyc = (own_bytes_per_cycle(eng.plan, recomputed) if eng.fused else algorithmic_bytes_per_cycle(eng.plan)) * nprob
         out = {
             "metric": "unknowns*V-cycles/s", "value": unknowns * args.steps / dt, "unit": "unknowns*V-cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -282,25 +343,35 @@ def main():
                 "n": n, "n_para": n_para, "grid": [gny, gnx], "batch": args.batch or None, "unknowns": unknowns,
                 "coarse_ordering": args.ordering, "jacobi_omega": args.jacobi_omega, "whole_domain_level": [eng.plan.whole[0].ny, eng.plan.whole[0].nx],
                 "parallelism": f"row-slab x{world}", "hipgraph": bool(eng.use_graph), "fused_passes": bool(eng.fused), "recompute_presmoothing": bool(eng.recompute_presmoothing and eng.fused),
+                "levels_with_recomputed_presmoothing": recomputed,
                 "placement": eng.placement, "placement_sampling_seconds": round(eng.placement_seconds, 2),
                 "halo_rows": eng.plan.halo, "distributed_levels": eng.n_dist if world > 1 else None,
                 "exchange_overlap": ({"min_rows_per_rank": eng.overlap_min_rows, "passes_cut": eng.split_passes,
                                       "rounds_per_cycle": eng.rounds_per_cycle()} if world > 1 else None),
                 "dead_whole_domain_levels": "computed every cycle" if eng.eager_dead_levels else "on demand", "backend": args.backend if world > 1 else None,
+                "ranks_seen": dist.get_world_size() if world > 1 else 1,
             },
+            # the cycle on arrays as the allocator hands them out (no placement selection), 5 cycles on an engine of its own
+            "untuned_ms_per_step": untuned_ms,
             "roofline": {
                 "kernel": dom_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": dom_ms, "launches_timed": iters,
-                "note": "algorithmic bytes = per-operation compulsory bytes x the operations one launch performs; a "
-                        "fused pass moves fewer bytes than that, which is how frac can exceed 1",
-                "pass_own_compulsory_bytes_per_launch": own_bpp * pts_launch,
-                "frac_of_peak_on_own_bytes": own_bpp * pts_launch / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                "bytes_per_launch": own_bytes_launch, "bytes_per_point": own_bpp, "points_per_launch": pts_launch,
+                "avg_launch_ms": dom_ms, "launches_timed": iters,
+                "note": "achieved = the bytes the launch itself must move (every array element it reads or writes, once) / "
+                        "its average duration by HIP events",
+                "algorithmic_equivalent": {
+                    "bytes_per_launch": alg_bytes_launch, "bytes_per_point": alg_bpp,
+                    "gbps_equivalent": alg_bytes_launch / (dom_ms * 1e-3) / 1e9,
+                    "note": "the operations of the launch priced one by one (prolongation 18, 6 sweeps x 24, residual 24, "
+                            "restriction 10 B per point): a throughput equivalent for comparison with unfused code, not a bandwidth",
+                },
                 "single_jacobi_sweep": single,
             },
             "cycle": {
-                "algorithmic_bytes": bcyc, "gbps_per_gpu": bcyc / world / (ms * 1e-3) / 1e9,
-                "frac_of_peak": bcyc / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "own_bytes": own_cyc, "gbps_per_gpu": own_cyc / world / (ms * 1e-3) / 1e9,
+                "frac_of_peak": own_cyc / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "algorithmic_equivalent_bytes": bcyc, "algorithmic_equivalent_gbps_per_gpu": bcyc / world / (ms * 1e-3) / 1e9,
                 "max_abs_r_after_last_cycle": errs[-1] if errs else None,
             },
         }

@@ -95,6 +95,21 @@ def lib():
     return _lib
 
 
+def sources_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile and include/mg_hip.h, by name): identifies the
+    kernel build that measurements kept under profiles/ (HBM traffic counters) belong to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   [os.path.join(_HERE, "csrc", "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "mg_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def check(rc):
     if rc:
         raise MgError(lib().mg_last_error().decode())

@@ -16,6 +16,8 @@
 // Grids too large for LDS use the same wavefront on global memory (correct but slow).
 //
 // MG_SOR_REDBLACK is the usual two-colour Gauss-Seidel, one launch per colour.
+#include <atomic>
+
 #include "mg_common.h"
 
 #define SOR_PF 8 // prefetch distance for b, in diagonals
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(1024) void mg_sor_wavefront_kernel(const double *__
 // stream without being updated, which supplies the bottom boundary to the row above.
 // The remaining waves of the workgroup only help to load the grid and to write x and r back.
 #define SORW_PF 8
-#define SORW_GUARD 32      // doubles in front of the grid in LDS (reads run up to 3 chunks past a row's end)
+#define SORW_GUARD 32      // doubles in front of the grid in LDS: >= 3 * SORW_PF + 8 (see sor_wave_sweep)
 #define SORW_GUARD_BACK 96 // behind it: the same, plus one dummy slot per lane for the writes of inactive cells
 
 template <int RPL, int DIR>
@@ -169,7 +171,7 @@ __device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, doubl
 {
     constexpr int PF = SORW_PF;
     const double a = 1.5, alpha = 1 - a, beta = a / 4;
-    int j[RPL];
+    int j[RPL]; // row of slot k, clamped to the bottom boundary row: lanes beyond it stream that row again (unused)
     bool inter[RPL];
     double *srow[RPL];
     int boff[RPL];
@@ -178,11 +180,15 @@ __device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, doubl
     const int nsteps = DIR > 0 ? ny + nx - 3 : ny + nx - 2; // last step: row ny-2 at column nx-2 / row 1 at column 1
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
-        j[k] = RPL * lane + 1 + k;
-        inter[k] = j[k] <= ny - 2;
-        const int jc = j[k] < ny - 1 ? j[k] : ny - 1;
-        srow[k] = sx + jc * ldl;
-        boff[k] = jc * ld;
+        const int jr = RPL * lane + 1 + k;
+        inter[k] = jr <= ny - 2;
+        // Every address below is derived from the clamped row, its column offsets included: a lane past the grid
+        // reads exactly what the bottom boundary row's lane reads.  So the lowest LDS offset any lane forms is that
+        // of row 1 at column -1 - 3*PF (backward sweep, three chunks of look-ahead), i.e. >= -SORW_GUARD for every
+        // grid of at least 3 columns, and the highest is row ny-1 at column nx + 3*PF, inside the back guard.
+        j[k] = jr < ny - 1 ? jr : ny - 1;
+        srow[k] = sx + j[k] * ldl;
+        boff[k] = j[k] * ld;
         self[k] = 0, lat[k] = 0;
     }
     struct Chunk {
@@ -321,6 +327,22 @@ __global__ __launch_bounds__(256) void mg_sor_rb_kernel(const double *__restrict
     }
 }
 
+// The LDS limit of a kernel is an attribute of the function PER DEVICE: it is set once on every device a launch is
+// made on (flags per device and kernel group; setting it twice from two host threads is harmless).
+#define SOR_MAX_DEVICES 64
+static std::atomic<unsigned char> g_lds_attr[SOR_MAX_DEVICES][2];
+static bool lds_attr_done(int which)
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= SOR_MAX_DEVICES) return false; // unknown: set it again
+    return g_lds_attr[d][which].load(std::memory_order_acquire) != 0;
+}
+static void lds_attr_mark(int which)
+{
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < SOR_MAX_DEVICES) g_lds_attr[d][which].store(1, std::memory_order_release);
+}
+
 int g_sor_single_wave = 1; // tuning knob "sor_single_wave": 0 = never, 1 = where it is faster, 2 = wherever it fits
 
 extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64 ld, double h, i64 iterations,
@@ -344,13 +366,12 @@ extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64
         // measured 1.6-2.6x ahead of the one-thread-per-row kernel with one or two rows per lane
         if (lds && ny - 1 <= 64 * 4 && ny * ld < ((i64)1 << 27) && (g_sor_single_wave == 2 || (g_sor_single_wave == 1 && ny - 1 <= 128))) {
             const size_t bytes = ((size_t)ny * ldl + SORW_GUARD + SORW_GUARD_BACK) * sizeof(double);
-            static bool wattr_set = false;
-            if (!wattr_set) {
+            if (!lds_attr_done(0)) {
                 const int cap = (MG_SOR_LDS_DOUBLES + SORW_GUARD + SORW_GUARD_BACK) * (int)sizeof(double);
                 MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                wattr_set = true;
+                lds_attr_mark(0);
             }
             const dim3 grid((unsigned)nbatch), block(256);
             if (ny - 1 <= 64)
@@ -367,12 +388,11 @@ extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64
         }
         if (lds) {
             const size_t bytes = (size_t)ny * ldl * sizeof(double);
-            static bool attr_set = false;
-            if (!attr_set) {
+            if (!lds_attr_done(1)) {
                 MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wavefront_kernel<true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            MG_SOR_LDS_DOUBLES * (int)sizeof(double)));
-                attr_set = true;
+                lds_attr_mark(1);
             }
             hipLaunchKernelGGL(mg_sor_wavefront_kernel<true>, dim3((unsigned)nbatch), dim3(nt), bytes, st, b, x, r, ny,
                                nx, ld, ldl, h2, (int)iterations, backward, bstride);

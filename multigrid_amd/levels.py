@@ -176,6 +176,19 @@ def algorithmic_bytes_per_cycle(plan, keep_ascent_residuals=False, fused_zero_sw
     return total
 
 
+def own_bytes_per_cycle(plan, recomputed=()):
+    """What the fused passes of one V-cycle themselves must move, in bytes (float64), every array element read or
+    written once per pass: the finest pass 28 B/pt (reads x, b and a quarter of a point of coarse x, writes x and
+    a quarter of coarse b); a coarse level with recomputed pre-smoothing 10 (descent: reads b, writes coarse b)
+    + 18 (ascent: reads b and coarse x, writes x); a coarse level that stores its pre-smoothed x 18 + 26.
+    `recomputed`: the levels that run in the recompute scheme.  The whole-domain levels (a few KB) are left out."""
+    total = 0
+    for l in range(plan.n_para):
+        pts = (((plan.gny - 1) >> l) + 1) * (((plan.gnx - 1) >> l) + 1)
+        total += (28 if (l == 0 or l in recomputed) else 44) * pts
+    return total
+
+
 SOR_LDS_DOUBLES = 20000  # MG_SOR_LDS_DOUBLES of include/mg_hip.h
 
 
@@ -213,12 +226,13 @@ def choose_n_dist(gny, gnx, n_para, world, halo, t_round=110e-6, gather_bw=100e9
       * the first replicated level's right-hand side is all-gathered: its bytes x (world-1)/world
         arrive at every rank at gather_bw (xGMI is point-to-point: a ring moves ~one link's worth);
       * every replicated level is computed by all ranks: its points x bytes_per_point at stream_rate.
-    Returns the k in 1..n_para with the least cost among those whose slabs hold at least `halo` rows."""
+    Returns the k in 1..n_para with the least cost among those make_plan accepts (slabs of at least `halo` rows,
+    rows per rank divisible by 2**k)."""
     R0 = (gny - 1) // world
     best, best_cost = 1, None
     for k in range(1, n_para + 1):
-        if (R0 >> (k - 1)) < max(halo, 1):
-            break
+        if (R0 >> (k - 1)) < max(halo, 1) or R0 % (1 << k):
+            break  # make_plan would refuse it: slabs shorter than the halo, or a slab boundary on an odd row
         pts = lambda l: (((gny - 1) >> l) + 1) * (((gnx - 1) >> l) + 1)  # noqa: E731
         cost = 2 * k * t_round + 8 * pts(k) * (world - 1) / world / gather_bw
         cost += sum(pts(l) for l in range(k, n_para)) * bytes_per_point / stream_rate

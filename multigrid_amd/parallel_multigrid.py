@@ -72,7 +72,7 @@ class BlockWorld:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.members = [None] * 4
         self._dl = None
-        self._pending = [None] * 4  # per rank: (err, it) of the last collective solve, not yet returned
+        self._pending = [[] for _ in range(4)]  # per rank: (err, it) of the collective solves it has not been handed yet
         self.verbose = True
 
     # ---- membership
@@ -80,7 +80,7 @@ class BlockWorld:
         if self.members[mg.rank] is not None and self.members[mg.rank] is not mg:
             # a new solver object for this rank replaces the old one (a new problem on the same world)
             self._dl = None
-            self._pending = [None] * 4
+            self._pending = [[] for _ in range(4)]
         self.members[mg.rank] = mg
 
     def _complete(self):
@@ -245,11 +245,17 @@ class BlockWorld:
         return t[:, : D.wl_m[level]].cpu().numpy()
 
     def _solve_for(self, rank):
-        if self._pending[rank] is None:
+        """solve() of one rank.  The four ranks of the reference call solve() together; here they call one after the
+        other, so a collective solve runs when a rank asks for a result it has not been handed yet, and every rank's
+        result of that round is queued until that rank asks.  Both calling patterns of the reference's drivers
+        therefore run one collective solve per round: all ranks per round (test/test.py:76-82), or rank after rank
+        with several solve() calls each (core/parallel_multigrid.py:384-415 executed rank by rank) -- in the second
+        pattern a rank's arrays hold the LAST round's values by the time a later rank reads an earlier round's error."""
+        if not self._pending[rank]:
             errs = self.solve_all()
-            self._pending = [(errs[k], self.members[k].it) for k in range(4)]
-        err, it = self._pending[rank]
-        self._pending[rank] = None
+            for k in range(4):
+                self._pending[k].append((errs[k], self.members[k].it))
+        err, it = self._pending[rank].pop(0)
         self.members[rank].it = it
         return err
 

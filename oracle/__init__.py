@@ -57,6 +57,8 @@ def lib():
         L.orc_blocks_array.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(_i64)]
         L.orc_blocks_array.restype = C.POINTER(C.c_double)
         L.orc_blocks_set_verbose.argtypes = [C.c_void_p, C.c_int]
+        L.orc_blocks_set_rank_parallel.argtypes = [C.c_void_p, C.c_int]
+        L.orc_blocks_set_max_cycles.argtypes = [C.c_void_p, C.c_int]
         L.orc_blocks_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_blocks_solve.restype = C.c_int
         L.orc_global_create.argtypes = [_i64, _i64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
@@ -153,10 +155,14 @@ def _view(ptr, ny, nx):
 class BlockSolver:
     """The reference's four Multigrid ranks in one process (state persists across solves)."""
 
-    def __init__(self, n, n_para, h0, eps):
+    def __init__(self, n, n_para, h0, eps, rank_parallel=False):
+        """rank_parallel: the four ranks' kernels run on four threads, one per rank, each kernel single-threaded
+        (the reference runs as four single-threaded MPI processes); otherwise rank after rank, every kernel on
+        all OpenMP threads.  The values are the same."""
         self._h = lib().orc_blocks_create(n, n_para, h0, eps)
         if not self._h:
             raise AssertionError("n_para < n required (core/parallel_multigrid.py:159)")
+        lib().orc_blocks_set_rank_parallel(self._h, int(rank_parallel))
         self.n, self.n_para, self.it = n, n_para, 0
         self.x = [self.array("x_sb", k, 0) for k in range(4)]
         self.b = [self.array("b_sb", k, 0) for k in range(4)]
@@ -169,6 +175,10 @@ class BlockSolver:
         if not p:
             raise IndexError((name, rank, level))
         return _view(p, side.value, side.value)
+
+    def set_max_cycles(self, m):
+        """Cap on the cycles of one solve (at most the reference's 100)."""
+        lib().orc_blocks_set_max_cycles(self._h, int(m))
 
     def solve(self):
         err = np.zeros(4)

@@ -35,6 +35,9 @@
 
 typedef int64_t i64;
 
+/* grids with fewer points run their loops on the calling thread: a parallel region costs more than it saves there */
+#define ORC_PAR_MIN 32768
+
 /* limit the row-parallel loops below to n host threads (timing the algorithm on as many workers
  * as the reference runs MPI ranks: 4) */
 void orc_set_num_threads(int n)
@@ -84,7 +87,7 @@ void orc_laplacian(const double *a, double *lplc, i64 ny, i64 nx, double h)
 void orc_residual(double *r, const double *a, const double *b, i64 ny, i64 nx, double h)
 {
     double hh = 1 / (h * h);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ny * nx >= ORC_PAR_MIN)
     for (i64 j = 1; j < ny - 1; j++) {
         double left = a[j * nx + 0] * hh;
         for (i64 i = 1; i < nx - 1; i++) {
@@ -101,12 +104,12 @@ void orc_residual(double *r, const double *a, const double *b, i64 ny, i64 nx, d
 void orc_smooth_sweep_jacobi(const double *b, double *a, double *a_temp, i64 ny, i64 nx, double h)
 {
     double h2 = h * h;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ny * nx >= ORC_PAR_MIN)
     for (i64 j = 1; j < ny - 1; j++)
         for (i64 i = 1; i < nx - 1; i++)
             a_temp[j * nx + i] = 0.25 * (a[j * nx + i + 1] + a[j * nx + i - 1] + a[(j + 1) * nx + i] +
                                          a[(j - 1) * nx + i] - h2 * b[j * nx + i]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ny * nx >= ORC_PAR_MIN)
     for (i64 j = 0; j < ny; j++)
         for (i64 i = 0; i < nx; i++)
             a[j * nx + i] = a_temp[j * nx + i];
@@ -120,14 +123,14 @@ void orc_smooth_sweep_jacobi(const double *b, double *a, double *a_temp, i64 ny,
 void orc_smooth_sweep_jacobi_damped(const double *b, double *a, double *a_temp, i64 ny, i64 nx, double h, double omega)
 {
     double h2 = h * h;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ny * nx >= ORC_PAR_MIN)
     for (i64 j = 1; j < ny - 1; j++)
         for (i64 i = 1; i < nx - 1; i++) {
             double t = 0.25 * (a[j * nx + i + 1] + a[j * nx + i - 1] + a[(j + 1) * nx + i] + a[(j - 1) * nx + i] -
                                h2 * b[j * nx + i]);
             a_temp[j * nx + i] = a[j * nx + i] + omega * (t - a[j * nx + i]);
         }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ny * nx >= ORC_PAR_MIN)
     for (i64 j = 0; j < ny; j++)
         for (i64 i = 0; i < nx; i++)
             a[j * nx + i] = a_temp[j * nx + i];
@@ -204,7 +207,7 @@ void orc_smooth_altern_rb(const double *b, double *x, double h, double *r, i64 i
 void orc_coarse(const double *a, i64 fny, i64 fnx, double *a_crs, i64 cny, i64 cnx, i64 ofst_i, i64 ofst_j)
 {
     (void)fny;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cny * cnx >= ORC_PAR_MIN)
     for (i64 j = 1; j < cny - 1; j++) {
         const double *am = a + (2 * j + ofst_j - 1) * fnx, *a0 = am + fnx, *ap = a0 + fnx;
         double a_left = a0[1 + ofst_i] / 8 + (ap[1 + ofst_i] + am[1 + ofst_i]) / 16;
@@ -224,7 +227,7 @@ void orc_interpolate_add_to(const double *a, i64 cny, i64 cnx, double *a_new, i6
                             i64 ofst_j)
 {
     (void)fny;
-#pragma omp parallel
+#pragma omp parallel if (cny * cnx >= ORC_PAR_MIN)
     {
 #pragma omp for schedule(static)
         for (i64 j = 1; j < cny - 1; j++)
@@ -251,7 +254,7 @@ double orc_maxabs(const double *a, i64 n)
 {
     double m = 0;
     int nan = 0;
-#pragma omp parallel for schedule(static) reduction(max : m) reduction(| : nan)
+#pragma omp parallel for schedule(static) reduction(max : m) reduction(| : nan) if (n >= ORC_PAR_MIN)
     for (i64 k = 0; k < n; k++) {
         double v = fabs(a[k]);
         if (v != v)
@@ -279,6 +282,8 @@ typedef struct {
     double *x_wl[MAXLEV], *b_wl[MAXLEV], *r_wl[MAXLEV];
     int it;
     int verbose;
+    int max_cycles;    /* cap on the cycles of one solve (MAXCYC = the reference's 100, :270) */
+    int rank_parallel; /* 1: the four ranks' kernels run on four threads, one per rank, as the reference's four processes do */
 } blocks_t;
 
 static double *zalloc(i64 n) { return (double *)calloc((size_t)n, sizeof(double)); }
@@ -290,6 +295,7 @@ void *orc_blocks_create(int n, int n_para, double h0, double eps)
         return NULL; /* the reference asserts n_para < n (:159) */
     blocks_t *s = (blocks_t *)calloc(1, sizeof(blocks_t));
     s->n = n, s->n_para = n_para, s->h0 = h0, s->eps = eps;
+    s->max_cycles = MAXCYC;
     s->nwl = 0;
     for (int i = n_para - 1; i < n; i++) { /* :182-192 */
         i64 m = ((i64)1 << (n - i)) + 1;
@@ -351,6 +357,14 @@ double *orc_blocks_array(void *hd, int which, int rank, int level, i64 *side)
 }
 
 void orc_blocks_set_verbose(void *hd, int v) { ((blocks_t *)hd)->verbose = v; }
+void orc_blocks_set_rank_parallel(void *hd, int v) { ((blocks_t *)hd)->rank_parallel = v; }
+void orc_blocks_set_max_cycles(void *hd, int m) { ((blocks_t *)hd)->max_cycles = m < 1 ? 1 : (m > MAXCYC ? MAXCYC : m); }
+
+/* Loop over the four ranks: serial (every kernel then uses all OpenMP threads over its rows), or one thread per
+ * rank with the kernels inside running single-threaded (nested regions are inactive), which is how the reference's
+ * four MPI processes share the work (core/Makefile:7).  The ranks are independent inside each such loop, so the
+ * values do not change. */
+#define FOR_RANKS(s) _Pragma("omp parallel for schedule(static, 1) num_threads(NRANK) if ((s)->rank_parallel)") for (int rk = 0; rk < NRANK; rk++)
 
 /*
  * Buffers.exchange_buffers for one variable on all four ranks, core/parallel_multigrid.py:19-97
@@ -395,15 +409,15 @@ static void exchange4(double *v[NRANK], i64 m)
 static void smooth_parallel4(blocks_t *s, double *b[NRANK], double *x[NRANK], double h, double *r[NRANK], i64 m,
                              int iterations)
 {
-    for (int rk = 0; rk < NRANK; rk++)
+    FOR_RANKS(s)
         memcpy(s->tmp[rk], x[rk], (size_t)(m * m) * sizeof(double)); /* :105-106, before the exchange */
     exchange4(x, m);
     for (int k = 0; k < iterations; k++) {
-        for (int rk = 0; rk < NRANK; rk++)
+        FOR_RANKS(s)
             orc_smooth_sweep_jacobi(b[rk], x[rk], s->tmp[rk], m, m, h);
         exchange4(x, m);
     }
-    for (int rk = 0; rk < NRANK; rk++)
+    FOR_RANKS(s)
         orc_residual(r[rk], x[rk], b[rk], m, m, h);
 }
 
@@ -453,11 +467,11 @@ int orc_blocks_solve(void *hd, double *err_out, double *err_hist, double *r_hist
     LV(x, 0); LV(b, 0); LV(r, 0);
     smooth_parallel4(s, b, x, s->h_sb[0], r, s->sb_n[0], 1); /* :264-266 */
 
-    while (status < 4 && s->it < MAXCYC) {
+    while (status < 4 && s->it < s->max_cycles) {
         /* descent, sub-domains */
         LV(r, 0);
         exchange4(r, s->sb_n[0]); /* :272 */
-        for (int rk = 0; rk < NRANK; rk++) {
+        FOR_RANKS(s) {
             if (r_hist)
                 r_hist[rk * MAXCYC + s->it] = orc_maxabs(r[rk], s->sb_n[0] * s->sb_n[0]);
             orc_coarse(r[rk], s->sb_n[0], s->sb_n[0], s->b_sb[rk][1], s->sb_n[1], s->sb_n[1], OFS_I[rk], OFS_J[rk]);
@@ -465,11 +479,11 @@ int orc_blocks_solve(void *hd, double *err_out, double *err_hist, double *r_hist
         for (int i = 1; i < n_para; i++) { /* :275-288 */
             i64 m = s->sb_n[i];
             LV(x, i); LV(b, i); LV(r, i);
-            for (int rk = 0; rk < NRANK; rk++)
+            FOR_RANKS(s)
                 memset(x[rk], 0, (size_t)(m * m) * sizeof(double));
             smooth_parallel4(s, b, x, s->h_sb[i], r, m, n1);
             exchange4(r, m);
-            for (int rk = 0; rk < NRANK; rk++)
+            FOR_RANKS(s)
                 orc_coarse(r[rk], m, m, s->b_sb[rk][i + 1], s->sb_n[i + 1], s->sb_n[i + 1], OFS_I[rk], OFS_J[rk]);
         }
         /* whole domain: identical on every rank, so computed once (:291-297) */
@@ -490,7 +504,7 @@ int orc_blocks_solve(void *hd, double *err_out, double *err_hist, double *r_hist
             orc_smooth_altern(s->b_wl[L - i], s->x_wl[L - i], s->h_wl[L - i], s->r_wl[L - i], n2, mf, mf);
         }
         /* ascent, sub-domains (:307-333) */
-        for (int rk = 0; rk < NRANK; rk++) {
+        FOR_RANKS(s) {
             orc_split(s->x_wl[0], s->wl_n[0], s->wl_n[0], s->b_sb[rk][n_para], s->sb_n[n_para], rk);
             orc_interpolate_add_to(s->b_sb[rk][n_para], s->sb_n[n_para], s->sb_n[n_para], s->x_sb[rk][n_para - 1],
                                    s->sb_n[n_para - 1], s->sb_n[n_para - 1], OFS_I[rk], OFS_J[rk]);
@@ -499,7 +513,7 @@ int orc_blocks_solve(void *hd, double *err_out, double *err_hist, double *r_hist
         smooth_parallel4(s, b, x, s->h_sb[n_para - 1], r, s->sb_n[n_para - 1], n2);
         for (int i = 2; i < n_para + 1; i++) {
             int lc = n_para - i + 1, lf = n_para - i;
-            for (int rk = 0; rk < NRANK; rk++)
+            FOR_RANKS(s)
                 orc_interpolate_add_to(s->x_sb[rk][lc], s->sb_n[lc], s->sb_n[lc], s->x_sb[rk][lf], s->sb_n[lf],
                                        s->sb_n[lf], OFS_I[rk], OFS_J[rk]);
             LV(b, lf); LV(x, lf); LV(r, lf);

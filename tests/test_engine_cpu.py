@@ -335,3 +335,25 @@ def test_cut_passes_partition_rows_and_stay_clear_of_the_halo():
                     assert T[0][0] == Lc.t0 and T[2][1] == Lc.t1 and T[0][1] == T[1][0] and T[1][1] == T[2][0]
                     for (j0, j1), (T0, T1) in zip(parts, T):
                         assert T0 < T1 and j0 <= 2 * T0 - H and 2 * (T1 - 1) - H < j1
+
+
+def test_choose_n_dist_only_proposes_plans_make_plan_accepts():
+    """The cost model ranks only slab depths whose plan exists: rows per rank divisible by 2**k and at least
+    `halo` rows on the coarsest distributed level (sizes with odd multiples of a power of two included)."""
+    from multigrid_amd.levels import choose_n_dist, make_plan
+    checked = 0
+    for world in (2, 3, 4, 8):
+        for cells in (400, 96, 1536, 200 * world, 48 * world, 4096, 2 ** 15, 3 * 2 ** 10):
+            for n_para in (1, 2, 3, 4, 6):
+                gny = cells + 1
+                try:
+                    make_plan(gny, 257, n_para, world, 0, halo=8, n_dist=1)
+                except ValueError:
+                    continue
+                for halo in (2, 8, 12):
+                    if (cells // world) < halo:
+                        continue
+                    k = choose_n_dist(gny, 257, n_para, world, halo)
+                    make_plan(gny, 257, n_para, world, 0, halo=halo, n_dist=k)  # must not raise
+                    checked += 1
+    assert checked > 50

@@ -72,6 +72,43 @@ def test_block_multigrid_reproduces_reference_runs(path):
     assert np.array_equal(full, full2)
 
 
+def test_rank_after_rank_calling_pattern_runs_one_solve_per_round():
+    """The reference module's script part calls solve() twice per rank (core/parallel_multigrid.py:384-415).  Executed
+    rank after rank -- rank 0 both calls, then rank 1 both calls, ... -- that is still two collective solves, and
+    every rank gets the first round's (err, it) from its first call and the second round's from its second."""
+    from multigrid_amd.parallel_multigrid import BlockWorld, Multigrid, split
+    g = np.load(os.path.join(GOLDEN, "solve_m_n5_p2.npz"))
+    n, n_para = int(g["n"]), int(g["n_para"])
+    b0, h = main_rhs(n)
+    world = BlockWorld()
+    world.verbose = False
+    solvers = []
+    for rank in range(4):
+        bk = np.zeros((2 ** n + 2, 2 ** n + 2))
+        split(b0, bk, rank)
+        solvers.append(Multigrid(bk, np.zeros_like(bk), np.zeros_like(bk), h, float(g["eps"]), n, n_para, rank=rank, world=world))
+    rounds = 0
+    orig = world.solve_all
+
+    def counting():
+        nonlocal rounds
+        rounds += 1
+        return orig()
+
+    world.solve_all = counting
+    errs, its = np.zeros((4, 2)), np.zeros((4, 2), dtype=int)
+    for rank in range(4):
+        for s in range(2):
+            errs[rank, s] = solvers[rank].solve()
+            its[rank, s] = solvers[rank].it
+    assert rounds == 2
+    assert np.array_equal(its, g["its"]) and np.array_equal(errs, g["errs"])
+    # a third call of one rank starts the third round, which the others then share
+    solvers[3].solve()
+    solvers[0].solve()
+    assert rounds == 3
+
+
 def test_multigrid_argument_checks():
     from multigrid_amd.parallel_multigrid import BlockWorld, Multigrid, MgError, offsets
     w = BlockWorld()

@@ -207,7 +207,7 @@ def test_batch_of_1024_problems_equals_oracle_on_sampled_problems():
     eng.close()
 
 
-def _two_rank_worker(rank, world, port, n, n_para, cycles, q):
+def _two_rank_worker(rank, world, port, n, n_para, cycles, q):  # started by tests.mp_util.run_ranks
     import torch
     import torch.distributed as dist
     import bench
@@ -240,33 +240,12 @@ def test_two_ranks_at_the_benchmark_slab_size_equal_one_rank():
     with their passes cut around the halo exchange) on two ranks that share the GPU (gloo, messages staged
     through the host): per-cycle norms equal those of one rank on the same 65537 x 32769 grid, and so do rows of
     x and r at the slab ends, next to them and inside."""
-    import socket
-
     import torch
-    import torch.multiprocessing as mp
     import bench
     from multigrid_amd.engine import SlabMultigrid
+    from tests.mp_util import run_ranks
     n, n_para, world, cycles = 14, 10, 2, 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(rk, world, port, n, n_para, cycles, q)) for rk in range(world)]
-    for p in procs:
-        p.start()
-    out = {}
-    try:
-        for _ in range(world):
-            msg = q.get(timeout=140)
-            out[msg[0]] = msg[1:]
-    finally:
-        for p in procs:
-            p.join(timeout=60)
-            if p.is_alive():
-                p.kill()
-    assert all(p.exitcode == 0 for p in procs)
+    out = run_ranks(_two_rank_worker, world, (n, n_para, cycles), timeout=200)
     one = SlabMultigrid(world * 2 ** (n + 1) + 1, 2 ** (n + 1) + 1, n_para, 20.0 / 2 ** (n + 1), 0.0, world=1, rank=0,
                         eager_dead_levels=True)
     bench.fill_rhs(one, torch, n, 0)

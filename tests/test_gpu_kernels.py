@@ -265,7 +265,7 @@ def test_transfer_whole_domain(mm, fshape, cshape):
     assert np.array_equal(df.cpu().numpy(), f_ref)
 
 
-SOR_SHAPES = [(3, 3), (4, 7), (9, 9), (33, 33), (65, 257), (129, 129), (141, 139), (1100, 9), (257, 257), (1030, 40),
+SOR_SHAPES = [(3, 3), (5, 5), (4, 7), (9, 9), (33, 33), (65, 257), (129, 129), (141, 139), (1100, 9), (257, 257), (1030, 40),
               (65, 65), (66, 40), (64, 200), (5, 1000), (128, 128), (130, 90), (200, 90), (257, 65), (258, 20), (17, 3), (3, 17)]
 
 

@@ -2,7 +2,6 @@
 schedule of the slab engine with the real HIP kernels, streams and the rank-0 tail graph.  Results
 must equal the single-rank engine / the undecomposed oracle bit for bit.  Marked gpu."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -12,15 +11,7 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows, kw=None):
+def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, fused, dist_min_rows, kw, q):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -66,7 +57,6 @@ def test_ranks_with_split_passes_equal_oracle(world, gny, gnx, n_para, dist_min_
 
 
 def _run(world, gny, gnx, n_para, fused, dist_min_rows, kw=None):
-    import torch.multiprocessing as mp
     rng = np.random.default_rng(1)
     b = rng.standard_normal((gny, gnx))
     b[0] = b[-1] = 0
@@ -75,20 +65,8 @@ def _run(world, gny, gnx, n_para, fused, dist_min_rows, kw=None):
     ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0)
     ref.b[:] = b
     ref.solve(ncycles=cycles)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, gny, gnx, n_para, h, b, cycles, q, fused, dist_min_rows, kw))
-             for rk in range(world)]
-    for p in procs:
-        p.start()
-    out = {}
-    for _ in range(world):
-        rank, errs, x, r = q.get(timeout=280)
-        out[rank] = (errs, x, r)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    from tests.mp_util import run_ranks
+    out = run_ranks(_worker, world, (gny, gnx, n_para, h, b, cycles, fused, dist_min_rows, kw))
     for k in range(world):
         assert out[k][0] == ref.err_hist.tolist()
     assert np.array_equal(np.concatenate([out[k][1] for k in range(world)]), ref.x)

@@ -34,12 +34,12 @@ BYTES = {
     "void mg_stencil5_kernel<1, 2, 1, true>": (16, 16),
     "void mg_restrict_kernel<true>": (10, 10),
     "void mg_prolong_kernel<true, true>": (18, 18),
-    "void mg_fused_kernel<6, true, false, true, false, 1, 0, false>": (18 + 6 * 24 + 24, 8 + 2 + 8 + 8 + 8),
-    "void mg_fused_kernel<3, false, true, true, false, 1, 0, false>": (16 + 2 * 24 + 24, 8 + 8 + 8),
-    "void mg_fused_kernel<6, true, false, false, false, 1, 0, false>": (18 + 6 * 24, 8 + 2 + 8 + 8),
-    "void mg_fused_kernel<6, true, false, true, true, 1, 0, false>": (18 + 6 * 24 + 24 + 10, 8 + 2 + 8 + 8 + 2),  # r not stored
-    "void mg_fused_kernel<3, false, true, true, true, 1, 0, false>": (16 + 2 * 24 + 24 + 10, 8 + 2),  # x not stored
-    "void mg_fused_kernel<9, true, true, false, false, 1, 3, false>": (16 + 2 * 24 + 18 + 6 * 24, 8 + 2 + 8),
+    "void mg_fused_kernel<6, true, false, true, false, 1, 0, false, true>": (18 + 6 * 24 + 24, 8 + 2 + 8 + 8 + 8),
+    "void mg_fused_kernel<3, false, true, true, false, 1, 0, false, true>": (16 + 2 * 24 + 24, 8 + 8 + 8),
+    "void mg_fused_kernel<6, true, false, false, false, 1, 0, false, true>": (18 + 6 * 24, 8 + 2 + 8 + 8),
+    "void mg_fused_kernel<6, true, false, true, true, 1, 0, false, true>": (18 + 6 * 24 + 24 + 10, 8 + 2 + 8 + 8 + 2),  # r not stored
+    "void mg_fused_kernel<3, false, true, true, true, 1, 0, false, true>": (16 + 2 * 24 + 24 + 10, 8 + 2),  # x not stored
+    "void mg_fused_kernel<9, true, true, false, false, 1, 3, false, true>": (16 + 2 * 24 + 18 + 6 * 24, 8 + 2 + 8),
 }
 
 
@@ -65,9 +65,12 @@ def main():
     def total(name):
         return kernels[name]["hbm_bytes"] if name in kernels else None
 
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    from multigrid_amd._lib import sources_digest
     out = {
+        "csrc_sha256": sources_digest(),
         "jacobi_finest_bytes_per_launch": total("void mg_stencil5_kernel<0, 2, 1, true>"),
-        "fused_finest_bytes_per_launch": total("void mg_fused_kernel<6, true, false, true, true, 1, 0, false>"),
+        "fused_finest_bytes_per_launch": total("void mg_fused_kernel<6, true, false, true, true, 1, 0, false, true>"),
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/pmc_probe.py, "
                 f"{2 ** (args.n + 1) + 1} squared; FETCH_SIZE (KiB) doubled per the gfx950 correction for 16-B/lane "
                 "streaming reads, WRITE_SIZE (KiB) as is; averages over the launches of each kernel",
