@@ -4,7 +4,8 @@
  * [-10, 10]^2, solved twice (the second solve warm-starts from the first), the reference's six lines
  * printed per solve, then max|b - A x| of the downloaded solution evaluated on the host.
  *
- *   poisson_main [n] [n_para]        (defaults 8 and 4, the reference's)
+ *   poisson_main [n] [n_para] [k]    (defaults 8 and 4, the reference's; k > 0: after the two solves, k more
+ *                                     V-cycles without stop test are timed, mg_solver_cycles)
  *
  * Large grids (from 1 GiB per array) let create pick the placement of the finest arrays.
  */
@@ -54,6 +55,18 @@ int main(int argc, char **argv)
         const double t = now() - t0;
         printf("nx = %lld\nn_para = %d\nm_err/b_max=%.1e\ntime %.3e s/point\ntime %.3e s\nv cycles %d\n", (long long)nx1, n_para,
                err / b_max, t / (double)(nx0 - 2), t, it);
+    }
+    const int k = argc > 3 ? atoi(argv[3]) : 0;
+    if (k > 0) {
+        double *errs = malloc(sizeof(double) * (size_t)k);
+        if (!errs) return 1;
+        CHECK(mg_solver_cycles(s, 2, errs)); /* warm-up */
+        const double t0 = now();
+        CHECK(mg_solver_cycles(s, k, errs));
+        const double t = now() - t0;
+        printf("%d cycles without stop test: %.4f ms per cycle, %.4g unknowns*V-cycles/s, last max|r| %.6e\n", k, 1e3 * t / k,
+               (double)(nx0 - 2) * (double)(nx0 - 2) * k / t, errs[k - 1]);
+        free(errs);
     }
     CHECK(mg_solver_download(s, MG_SOLVER_X, 0, x, nx0));
     double rmax = 0;

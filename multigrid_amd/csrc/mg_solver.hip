@@ -47,7 +47,11 @@ struct mg_solver {
     std::vector<JLevel> lv;
     std::vector<WLevel> wl;
     std::vector<void *> allocs;
-    u64 *norm;
+    u64 *norm[2];      // two max-norm accumulators, used in turn: the one the finest x's array at the start of a cycle selects
+    u64 *host_norm[2]; // pinned host copies of them
+    hipStream_t copy;  // reads a cycle's accumulator back while the next cycle runs
+    hipEvent_t filled[2], fetched[2];
+    int last_acc;      // accumulator the last cycle filled
     hipStream_t stream, side;
     hipEvent_t fork, join;
     hipGraphExec_t graphs[2][2]; // [array the finest x starts in][finest residual stored]
@@ -117,10 +121,12 @@ int finest_pass(mg_solver *s, int sweeps, const double *crs, i64 cny, i64 cnx, i
     double *cb;
     i64 bny, bnx, bld;
     coarse_of(s, 0, &cb, &bny, &bnx, &bld);
-    if (want_norm && mg_norm_reset((uint64_t *)s->norm, s->stream)) return 1;
+    u64 *const acc = s->norm[s->cur0]; // cur0 at the start of the pass: a captured graph always fills the same one
+    if (want_norm) s->last_acc = s->cur0;
+    if (want_norm && mg_norm_reset((uint64_t *)acc, s->stream)) return 1;
     if (mg_smooth_fused_restrict(L.b, xs[s->cur0], xs[1 - s->cur0], store_r ? L.r : nullptr, crs, L.ny, L.nx, L.ld, cny, cnx,
                                  cld, 1, L.ny - 1, 0, L.ny - 1, 0, sweeps, L.h, s->omega,
-                                 want_norm ? (uint64_t *)s->norm : nullptr, cb, bny, bnx, bld, 1, bny - 1, 1, 0, 0, 0,
+                                 want_norm ? (uint64_t *)acc : nullptr, cb, bny, bnx, bld, 1, bny - 1, 1, 0, 0, 0,
                                  s->stream))
         return 1;
     s->cur0 = 1 - s->cur0;
@@ -220,7 +226,7 @@ int run_cycle(mg_solver *s, bool store_r)
     if (!s->use_graph) return cycle(s, store_r);
     if (!s->graphs[s->cur0][store_r]) {
         // capture every variant now (capturing records, it does not execute)
-        const int cur = s->cur0;
+        const int cur = s->cur0, acc = s->last_acc;
         const bool stale = s->r_stale;
         for (int start = 0; start < 2; ++start)
             for (int sr = 0; sr < 2; ++sr) {
@@ -230,16 +236,17 @@ int run_cycle(mg_solver *s, bool store_r)
                 const int rc = cycle(s, sr != 0);
                 void *g = nullptr;
                 if (mg_graph_end(s->stream, &g) || rc) {
-                    s->cur0 = cur, s->r_stale = stale;
+                    s->cur0 = cur, s->r_stale = stale, s->last_acc = acc;
                     if (g) mg_graph_destroy(g);
                     return 1;
                 }
                 s->graphs[start][sr] = (hipGraphExec_t)g;
                 s->graph_end_cur[start] = s->cur0;
             }
-        s->cur0 = cur, s->r_stale = stale;
+        s->cur0 = cur, s->r_stale = stale, s->last_acc = acc;
     }
     if (mg_graph_launch(s->graphs[s->cur0][store_r], s->stream)) return 1;
+    s->last_acc = s->cur0; // the accumulator that graph fills
     s->cur0 = s->graph_end_cur[s->cur0];
     s->r_stale = !store_r;
     return 0;
@@ -255,7 +262,31 @@ int materialize_residual(mg_solver *s)
     return 0;
 }
 
-int read_err(mg_solver *s, double *err) { return mg_norm_read((const uint64_t *)s->norm, err, s->stream); }
+// max|r| of the last cycle, now (waits for the stream)
+int read_err(mg_solver *s, double *err) { return mg_norm_read((const uint64_t *)s->norm[s->last_acc], err, s->stream); }
+
+// Read-back of accumulator `a` as it stands at this point of the main stream, on the copy stream: the host
+// collects it (collect_err) after it has enqueued the next cycle, so the GPU does not idle while the host waits
+// for the number and launches the next graph.
+int fetch_err(mg_solver *s, int a)
+{
+    MG_HIP(hipEventRecord(s->filled[a], s->stream));
+    MG_HIP(hipStreamWaitEvent(s->copy, s->filled[a], 0));
+    MG_HIP(hipMemcpyAsync(s->host_norm[a], s->norm[a], MG_NORM_SLOTS * sizeof(u64), hipMemcpyDeviceToHost, s->copy));
+    MG_HIP(hipEventRecord(s->fetched[a], s->copy));
+    return 0;
+}
+
+int collect_err(mg_solver *s, int a, double *err)
+{
+    MG_HIP(hipEventSynchronize(s->fetched[a]));
+    u64 m = 0;
+    for (int k = 0; k < MG_NORM_SLOTS; ++k) m = s->host_norm[a][k] > m ? s->host_norm[a][k] : m;
+    union { u64 u; double d; } cv;
+    cv.u = m;
+    *err = cv.d;
+    return 0;
+}
 
 // The same launch of the finest pass takes 5.4 or 6.1 ms at 32769 x 32769 depending on which allocations it
 // WRITES: x and the coarse right-hand side; the arrays it only reads matter by 2-3 %.  What decides is the
@@ -394,7 +425,9 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
     s->eager_dead = !(flags & MG_SOLVER_LAZY_DEAD_LEVELS);
     s->omega = 1.0, s->max_cycles = 100; // :270
     s->recompute_min_nx = 1024, s->recompute_min_blocks = 1024;
-    s->norm = nullptr, s->stream = s->side = nullptr, s->fork = s->join = nullptr;
+    s->norm[0] = s->norm[1] = nullptr, s->host_norm[0] = s->host_norm[1] = nullptr, s->last_acc = 0;
+    s->stream = s->side = s->copy = nullptr, s->fork = s->join = nullptr;
+    s->filled[0] = s->filled[1] = s->fetched[0] = s->fetched[1] = nullptr;
     s->cur0 = 0, s->r_stale = true, s->it = 0, s->diverged = false, s->placement_candidates = -1;
     for (int a = 0; a < 2; ++a) s->graphs[a][0] = s->graphs[a][1] = nullptr, s->graph_end_cur[a] = 0;
     int rc = 1;
@@ -402,6 +435,13 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
         if (hipGetDevice(&s->device) != hipSuccess) { mg_set_error("mg_solver_create: no current device"); break; }
         if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s->filled[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->filled[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->fetched[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->fetched[1], hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void **)&s->host_norm[0], MG_NORM_SLOTS * sizeof(u64), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&s->host_norm[1], MG_NORM_SLOTS * sizeof(u64), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) {
             mg_set_error("mg_solver_create: cannot create streams/events");
@@ -446,9 +486,9 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
             s->wl.push_back(W);
         }
         if (!ok) break;
-        double *nrm = nullptr;
-        if (dev_alloc(s, &nrm, MG_NORM_SLOTS)) break;
-        s->norm = (u64 *)nrm;
+        double *nrm[2] = {nullptr, nullptr};
+        if (dev_alloc(s, &nrm[0], MG_NORM_SLOTS) || dev_alloc(s, &nrm[1], MG_NORM_SLOTS)) break;
+        s->norm[0] = (u64 *)nrm[0], s->norm[1] = (u64 *)nrm[1];
         if (hipStreamSynchronize(s->stream) != hipSuccess) { mg_set_error("mg_solver_create: device error"); break; }
         decide_recompute(s);
         rc = 0;
@@ -466,10 +506,17 @@ extern "C" int mg_solver_destroy(mg_solver *s)
     if (!s) return 0;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->side) (void)hipStreamSynchronize(s->side);
+    if (s->copy) (void)hipStreamSynchronize(s->copy);
     drop_graphs(s);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->join) (void)hipEventDestroy(s->join);
+    for (int a = 0; a < 2; ++a) {
+        if (s->filled[a]) (void)hipEventDestroy(s->filled[a]);
+        if (s->fetched[a]) (void)hipEventDestroy(s->fetched[a]);
+        if (s->host_norm[a]) (void)hipHostFree(s->host_norm[a]);
+    }
+    if (s->copy) (void)hipStreamDestroy(s->copy);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -588,12 +635,34 @@ extern "C" int mg_solver_cycles(mg_solver *s, int k, double *errs)
 {
     if (check_device(s, "mg_solver_cycles")) return 1;
     MG_REQUIRE(k >= 0, "mg_solver_cycles: negative cycle count");
+    // Every cycle's norm is read, but one cycle late: cycle c fills the accumulator its starting array selects, its
+    // read-back is queued on the copy stream, and the host waits for the number only after it has enqueued cycle
+    // c + 1 (which fills the other accumulator).  Should two cycles in a row fill the same accumulator, the first is
+    // collected before the second is enqueued.
+    int pending = -1, pending_cycle = -1;
     for (int c = 0; c < k; ++c) {
+        if (pending >= 0 && pending == s->cur0) { // the next cycle resets the accumulator still to be collected
+            double e;
+            if (collect_err(s, pending, &e)) return 1;
+            if (errs) errs[pending_cycle] = e;
+            pending = -1;
+        }
         if (run_cycle(s, c == k - 1)) return 1; // the last pass leaves the residual array current
-        double e;
-        if (read_err(s, &e)) return 1;
-        if (errs) errs[c] = e;
+        const int a = s->last_acc;
+        if (fetch_err(s, a)) return 1;
+        if (pending >= 0) {
+            double e;
+            if (collect_err(s, pending, &e)) return 1;
+            if (errs) errs[pending_cycle] = e;
+        }
+        pending = a, pending_cycle = c;
     }
+    if (pending >= 0) {
+        double e;
+        if (collect_err(s, pending, &e)) return 1;
+        if (errs) errs[pending_cycle] = e;
+    }
+    MG_HIP(hipStreamSynchronize(s->stream));
     return 0;
 }
 

@@ -189,3 +189,41 @@ def test_tuned_placement_changes_nothing_but_where_the_arrays_lie():
     s = NativeSolver(257, 257, 3, 0.3, tune_placement=True)
     assert s.placement_candidates is None
     s.close()
+
+
+def test_handle_cycles_run_at_the_engines_rate():
+    """mg_solver_cycles reads every cycle's norm one cycle late, like SlabMultigrid.cycles: same numbers, and per
+    cycle no slower than the Python engine on the same grid (8193 x 8193, the cycle takes a millisecond there, so the
+    0.1 ms the host would otherwise spend waiting for each number and launching the next graph would show)."""
+    import time
+
+    import torch
+
+    from multigrid_amd.engine import SlabMultigrid
+    from multigrid_amd.solver import NativeSolver
+    gny = gnx = 8193
+    n_para, h, k = 8, 20.0 / 8192, 40
+    b = _rhs(gny, gnx, 7)
+    s = NativeSolver(gny, gnx, n_para, h)
+    s.upload("b", b)
+    s.presmooth()
+    s.cycles(3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e_handle = s.cycles(k)
+    t_handle = (time.perf_counter() - t0) / k
+    eng = SlabMultigrid(gny, gnx, n_para, h, 0.0, world=1, rank=0, eager_dead_levels=True)
+    eng.set_b_rows(torch.from_numpy(b).cuda())
+    eng.presmooth()
+    eng.cycles(3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e_engine = eng.cycles(k)
+    torch.cuda.synchronize()
+    t_engine = (time.perf_counter() - t0) / k
+    assert e_handle == e_engine
+    print(f"handle {1e3 * t_handle:.4f} ms per cycle, engine {1e3 * t_engine:.4f} ms per cycle")
+    assert t_handle <= 1.05 * t_engine, (t_handle, t_engine)
+    assert np.array_equal(s.download("x"), eng.local_rows(eng.x0).cpu().numpy())
+    s.close()
+    eng.close()
