@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 5
+#define MG_ABI_VERSION 6
 
 /* flags for the stencil entry points */
 #define MG_FLAG_FINEST 1 /* marks the launches of the finest level; ignored (large outputs get an instantiation of their own, see "stream_min_mib") */
@@ -168,11 +168,14 @@ int mg_smooth_fused(const double *b, const double *x_in, double *x_out, double *
  * x_out may be NULL too: then only coarse_b (and the norm) come out of the pass.
  * Replaces the residual + exchange + coarse sequence of core/parallel_multigrid.py:114,:272-273,
  * :287-288.  Reads rows j0-D .. j1+D-1 with D = sweeps + 2.
+ * norm_stride: 0 = one max-norm accumulator for all grids of a batch (as mg_smooth_fused); >= MG_NORM_SLOTS = grid g
+ * accumulates into the MG_NORM_SLOTS words at norm_slots + g * norm_stride, so that every problem of a batch has
+ * its own max|r| (the stop test of independent problems, core/parallel_multigrid.py:336-345 per problem).
  */
 int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out, double *r, const double *crs,
                              int64_t ny, int64_t nx, int64_t ld, int64_t cny, int64_t cnx, int64_t cld,
                              int64_t j0, int64_t j1, int64_t fix_lo, int64_t fix_hi, int64_t ofst_j, int sweeps,
-                             double h, double omega, uint64_t *norm_slots, double *coarse_b, int64_t cbny, int64_t cbnx,
+                             double h, double omega, uint64_t *norm_slots, int64_t norm_stride, double *coarse_b, int64_t cbny, int64_t cbnx,
                              int64_t cbld, int64_t T0, int64_t T1, int64_t nbatch, int64_t bstride,
                              int64_t cstride, int64_t cbstride, void *stream);
 /* Tuning knobs of mg_smooth_fused: column pairs per lane (1 or 2), rows per tile (0 = automatic). */

@@ -60,7 +60,7 @@ extern template int launch_fused<9, true, true, false, false, 1, 3, true>(FusedA
 static int smooth_fused_impl(const double *b, const double *x_in, double *x_out, double *r, const double *crs, i64 ny,
                              i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0, i64 j1, i64 fix_lo, i64 fix_hi,
                              i64 ofst_j, int sweeps, int prolong_after, double h, double omega, uint64_t *norm_slots,
-                             bool want_resid, double *coarse_b,
+                             i64 norm_stride, bool want_resid, double *coarse_b,
                              i64 cbny, i64 cbnx, i64 cbld, i64 T0, i64 T1, i64 nbatch, i64 bstride, i64 cstride,
                              i64 cbstride, void *stream)
 {
@@ -77,6 +77,7 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
         MG_REQUIRE(sweeps >= 1 && sweeps <= 6, "mg_smooth_fused: 1..6 sweeps per pass, got %d", sweeps);
     }
     MG_REQUIRE(omega > 0 && omega <= 1, "mg_smooth_fused: omega %g outside (0, 1]", omega);
+    MG_REQUIRE(norm_stride == 0 || norm_stride >= MG_NORM_SLOTS, "mg_smooth_fused_restrict: norm_stride must be 0 or >= %d", MG_NORM_SLOTS);
     MG_REQUIRE(ny >= 3 && nx >= 3 && ld >= nx, "mg_smooth_fused: bad shape");
     MG_REQUIRE(ld % 2 == 0 && mg_aligned(b, 16) && (!x_out || mg_aligned(x_out, 16)) && (!x_in || mg_aligned(x_in, 16)) &&
                    (!r || mg_aligned(r, 16)),
@@ -116,7 +117,7 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
     a.b = b, a.xin = x_in, a.xout = x_out, a.r = r, a.crs = crs;
     a.ny = ny, a.nx = nx, a.ld = ld, a.cny = cny, a.cnx = cnx, a.cld = cld;
     a.j0 = j0, a.j1 = j1, a.flo = fix_lo, a.fhi = fix_hi, a.oj = (int)ofst_j;
-    a.h2 = h * h, a.hh = 1 / (h * h), a.om = omega, a.norm = (u64 *)norm_slots;
+    a.h2 = h * h, a.hh = 1 / (h * h), a.om = omega, a.norm = (u64 *)norm_slots, a.norm_stride = norm_stride;
     a.rpb = a.ncb = a.nrc = a.ntc = a.stagger = 0;
     a.cb = coarse_b, a.cbnx = cbnx, a.cbld = cbld, a.T0 = T0, a.T1 = T1;
     a.nbatch = nbatch, a.bstride = bstride, a.cstride = cstride, a.cbstride = cbstride;
@@ -155,18 +156,18 @@ extern "C" int mg_smooth_fused(const double *b, const double *x_in, double *x_ou
                                uint64_t *norm_slots, i64 nbatch, i64 bstride, i64 cstride, void *stream)
 {
     return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
-                             prolong_after, h, omega, norm_slots, r != nullptr, nullptr, 0, 0, 0, 0, 0, nbatch, bstride,
+                             prolong_after, h, omega, norm_slots, 0, r != nullptr, nullptr, 0, 0, 0, 0, 0, nbatch, bstride,
                              cstride, 0, stream);
 }
 
 extern "C" int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out, double *r,
                                         const double *crs, i64 ny, i64 nx, i64 ld, i64 cny, i64 cnx, i64 cld, i64 j0,
                                         i64 j1, i64 fix_lo, i64 fix_hi, i64 ofst_j, int sweeps, double h, double omega,
-                                        uint64_t *norm_slots, double *coarse_b, i64 cbny, i64 cbnx, i64 cbld, i64 T0,
+                                        uint64_t *norm_slots, i64 norm_stride, double *coarse_b, i64 cbny, i64 cbnx, i64 cbld, i64 T0,
                                         i64 T1, i64 nbatch, i64 bstride, i64 cstride, i64 cbstride, void *stream)
 {
     MG_REQUIRE(coarse_b, "mg_smooth_fused_restrict: null coarse array");
     return smooth_fused_impl(b, x_in, x_out, r, crs, ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, ofst_j, sweeps,
-                             0, h, omega, norm_slots, true, coarse_b, cbny, cbnx, cbld, T0, T1, nbatch, bstride, cstride,
+                             0, h, omega, norm_slots, norm_stride, true, coarse_b, cbny, cbnx, cbld, T0, T1, nbatch, bstride, cstride,
                              cbstride, stream);
 }

@@ -19,6 +19,7 @@ struct FusedArgs {
     double h2, hh;
     double om; // damped Jacobi: x + om * (t - x), t the undamped value (DAMPED instantiations only)
     u64 *norm;
+    i64 norm_stride;     // words between the accumulators of consecutive grids of a batch; 0: one accumulator for all
     double *cb;          // coarse right-hand side produced by the fused restriction (RESTRICT)
     i64 cbnx, cbld, T0, T1; // its columns, leading dimension, and the coarse rows to produce
     i64 nbatch, bstride, cstride, cbstride; // number of grids; elements between consecutive grids of a batch: fine arrays, crs, cb
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
         if (a.r) a.r += g * a.bstride;
         if (a.crs) a.crs += g * a.cstride;
         if (a.cb) a.cb += g * a.cbstride;
+        if (a.norm) a.norm += g * a.norm_stride;
     }
     static_assert(!RESTRICT || RESID, "the restriction consumes the residual stage");
     constexpr int D = K + (RESID ? 1 : 0);   // pipeline stages that hold a three-row window

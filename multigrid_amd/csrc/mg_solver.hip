@@ -126,7 +126,7 @@ int finest_pass(mg_solver *s, int sweeps, const double *crs, i64 cny, i64 cnx, i
     if (want_norm && mg_norm_reset((uint64_t *)acc, s->stream)) return 1;
     if (mg_smooth_fused_restrict(L.b, xs[s->cur0], xs[1 - s->cur0], store_r ? L.r : nullptr, crs, L.ny, L.nx, L.ld, cny, cnx,
                                  cld, 1, L.ny - 1, 0, L.ny - 1, 0, sweeps, L.h, s->omega,
-                                 want_norm ? (uint64_t *)acc : nullptr, cb, bny, bnx, bld, 1, bny - 1, 1, 0, 0, 0,
+                                 want_norm ? (uint64_t *)acc : nullptr, 0, cb, bny, bnx, bld, 1, bny - 1, 1, 0, 0, 0,
                                  s->stream))
         return 1;
     s->cur0 = 1 - s->cur0;
@@ -165,7 +165,7 @@ int cycle(mg_solver *s, bool store_r)
         i64 bny, bnx, bld;
         coarse_of(s, l, &cb, &bny, &bnx, &bld);
         if (mg_smooth_fused_restrict(L.b, nullptr, L.recompute ? nullptr : L.xa, nullptr, nullptr, L.ny, L.nx, L.ld, 0, 0, 0,
-                                     1, L.ny - 1, 0, L.ny - 1, 0, N1, L.h, s->omega, nullptr, cb, bny, bnx, bld, 1, bny - 1, 1,
+                                     1, L.ny - 1, 0, L.ny - 1, 0, N1, L.h, s->omega, nullptr, 0, cb, bny, bnx, bld, 1, bny - 1, 1,
                                      0, 0, 0, st))
             return 1;
     }
@@ -327,7 +327,7 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out)
         bool good = true;
         for (int rep = 0; rep < 3 && good; ++rep) {
             good = !mg_smooth_fused_restrict(b, xin, xout, nullptr, crs, ny, nx, ld, cny, cnx, cld, 1, ny - 1, 0, ny - 1, 0, N2,
-                                             s->h0, 1.0, (uint64_t *)norm, cb, cny, cnx, cld, 1, cny - 1, 1, 0, 0, 0, s->stream);
+                                             s->h0, 1.0, (uint64_t *)norm, 0, cb, cny, cnx, cld, 1, cny - 1, 1, 0, 0, 0, s->stream);
             if (rep == 0) good = good && hipEventRecord(e0, s->stream) == hipSuccess;
         }
         good = good && hipEventRecord(e1, s->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&

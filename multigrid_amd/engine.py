@@ -49,7 +49,7 @@ class SlabMultigrid:
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
                  store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
                  recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=False,
-                 overlap_min_rows=4096):
+                 overlap_min_rows=4096, batch_stop="max"):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -123,6 +123,16 @@ class SlabMultigrid:
         if batch is not None and world != 1:
             raise ValueError("batched solves run on one rank")
         self.batch = batch
+        # batch_stop: what solve() applies the reference's stop rule (:336-345) to.  "max": the maximum of max|r|
+        # over the batch, all problems run the same number of cycles.  "each": every problem on its own -- it stops
+        # at the cycle at which its own solve() would stop and keeps the x it had then (the batch goes on until the
+        # last problem is done; a finished problem's further cycles are computed and discarded).
+        if batch_stop not in ("max", "each"):
+            raise ValueError("batch_stop must be 'max' or 'each'")
+        if batch_stop == "each" and (batch is None or not self.fused):
+            raise ValueError("batch_stop='each' is for batched solves with fused passes")
+        self.batch_stop = batch_stop
+        self.problem_its = self.problem_errs = self.problem_diverged = None
         z = (lambda rows, ld: ops.zeros(rows, ld, batch)) if batch is not None else ops.zeros
         # Jacobi levels: two x arrays (ping-pong), b, r.  b has one more level (the staging level).
         LV = self.lv
@@ -148,7 +158,10 @@ class SlabMultigrid:
         self._cur0 = 0  # which of (_xa[0], _xb[0]) holds the finest x
         # two accumulators, used in turn (the one the finest x's parity selects): the host can read a cycle's
         # norm while the next cycle, which resets and fills the other one, is already running
-        self._norms = [ops.norm_slots(), ops.norm_slots()]
+        if batch_stop == "each":
+            self._norms = [ops.norm_slots_per_problem(batch), ops.norm_slots_per_problem(batch)]
+        else:
+            self._norms = [ops.norm_slots(), ops.norm_slots()]
         self.norm = self._norms[0]
         # Whole-domain levels, on every rank.  The first one shares the rows of the (replicated)
         # staging level: local row t of the padded arrays is global row t - H.
@@ -802,8 +815,58 @@ class SlabMultigrid:
         self._flush_pending()
         self.ops.end()
 
+    def _solve_each(self):
+        """solve() with the stop rule applied to every problem of the batch on its own (batch_stop='each')."""
+        import numpy as np
+        B = self.batch
+        self.it, self.err_history, self.diverged = 0, [], False
+        its = np.zeros(B, dtype=np.int64)
+        errs = np.zeros(B)
+        err_old = np.full(B, 100.0)
+        diverged = np.zeros(B, dtype=bool)
+        active = np.ones(B, dtype=bool)
+        kept = None  # x of the problems that are done, as it was when they stopped
+        saved = np.zeros(B, dtype=bool)
+        self.presmooth()
+        self.ops.begin()
+        while active.any() and self.it < self.max_cycles:
+            self._run_cycle()
+            per = self.ops.norm_read_per_problem(self._norms[self._last_parity])
+            self.it += 1
+            self.err_history.append(float("nan") if np.isnan(per).any() else float(per.max()))
+            errs[active] = per[active]
+            its[active] = self.it
+            newly_div = active & (per > err_old * 1.1)
+            if newly_div.any():
+                print("Convergence compromised : r>r+1, set n1 higher")
+            diverged |= newly_div
+            err_old[active] = per[active]
+            done_now = active & ~((per > self.epsilon) & ~diverged)  # NaN compares false: such a problem stops, as in solve()
+            active &= ~done_now
+            if done_now.any() and active.any():  # others go on: keep what the finished ones have now
+                if kept is None:
+                    kept = torch.empty_like(self.x0)
+                idx = torch.from_numpy(np.flatnonzero(done_now)).to(self.x0.device)
+                with self.ops.ctx():
+                    kept[idx] = self.x0[idx]
+                saved |= done_now
+        if saved.any():
+            idx = torch.from_numpy(np.flatnonzero(saved)).to(self.x0.device)
+            with self.ops.ctx():
+                for arr in (self._xa[0], self._xb[0]):  # both, so that boundary values keep agreeing
+                    arr[idx] = kept[idx]
+            self._r0_stale = True
+        self._flush_pending()
+        self.ops.end()
+        self.materialize_residual()
+        self.problem_its, self.problem_errs, self.problem_diverged = its, errs, diverged
+        self.diverged = bool(diverged.any())
+        return float(errs.max()) if not np.isnan(errs).any() else float("nan")
+
     def solve(self):
         """Multigrid.solve(): returns max|r| over the whole grid after the last cycle."""
+        if self.batch_stop == "each":
+            return self._solve_each()
         self.it = 0
         self.err_history = []
         self.diverged = False

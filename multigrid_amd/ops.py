@@ -9,6 +9,7 @@ import ctypes as C
 
 import os
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -188,8 +189,10 @@ class HipOps:
         else:
             _, cbs, cbny, cbld = self._nb(coarse_b)
             assert prolong_after == 0
-            check(self.L.mg_smooth_fused_restrict(*common, h, omega, p(norm), p(coarse_b), cbny, cbnx, cbld, T0, T1, nb, bs, cs, cbs,
-                                                  self._s))
+            # a (batch, slots) accumulator: every problem of the batch has its own max-norm
+            nstride = norm.stride(0) if (norm is not None and norm.dim() == 2) else 0
+            check(self.L.mg_smooth_fused_restrict(*common, h, omega, p(norm), nstride, p(coarse_b), cbny, cbnx, cbld, T0, T1, nb,
+                                                  bs, cs, cbs, self._s))
 
     def sor(self, b, x, r, nx, h, iterations, ordering):
         self._same_layout(b, x, r)
@@ -198,11 +201,27 @@ class HipOps:
                             iterations, 1, {"lexicographic": _lib.SOR_LEXICOGRAPHIC, "redblack": _lib.SOR_REDBLACK}[ordering],
                             nb, bs, self._s))
 
+    def norm_slots_per_problem(self, batch):
+        """One accumulator per problem of a batch: a (batch, slots) tensor."""
+        return torch.zeros((batch, _lib.NORM_SLOTS), dtype=torch.int64, device=self.device)
+
     def norm_reset(self, slots):
-        check(self.L.mg_norm_reset(slots.data_ptr(), self._s))
+        if slots.dim() == 2:
+            check(self.L.mg_zero(slots.data_ptr(), slots.numel(), self._s))  # 8-byte words, like doubles
+        else:
+            check(self.L.mg_norm_reset(slots.data_ptr(), self._s))
+
+    def norm_read_per_problem(self, slots):
+        """max|r| of every problem from a (batch, slots) accumulator (a float64 numpy array); waits for the stream.
+        The accumulator holds bit patterns of |r|, whose integer order is the order of the values (NaN on top)."""
+        with self.ctx():
+            return slots.max(dim=1).values.view(torch.float64).cpu().numpy()
 
     def norm_read(self, slots):
         """max of the accumulator; waits for the stream."""
+        if slots.dim() == 2:
+            per = self.norm_read_per_problem(slots)
+            return float("nan") if np.isnan(per).any() else float(per.max())
         out = C.c_double()
         check(self.L.mg_norm_read(slots.data_ptr(), C.byref(out), self._s))
         return out.value
@@ -213,6 +232,10 @@ class HipOps:
         if self._copy is None:
             self._copy = torch.cuda.Stream(self.device)
         self._copy.wait_event(mark)
+        if slots.dim() == 2:
+            with torch.cuda.stream(self._copy):
+                per = slots.max(dim=1).values.view(torch.float64).cpu().numpy()
+            return float("nan") if np.isnan(per).any() else float(per.max())
         out = C.c_double()
         check(self.L.mg_norm_read(slots.data_ptr(), C.byref(out), self._copy.cuda_stream))
         return out.value

@@ -126,6 +126,62 @@ def test_batch_of_problems_equals_independent_solves(B, N, n_para, graph):
     eng.close()
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_batch_stops_every_problem_on_its_own(graph):
+    """batch_stop='each': right-hand sides of different scale in one batch; every problem stops at the cycle at which
+    its own solve() stops and ends with that solve's x, r, cycle count and max|r| (independent oracle runs), also on a
+    second, warm-started solve; one problem carries a NaN and stops at once with a NaN."""
+    import torch
+    from multigrid_amd.engine import SlabMultigrid
+    B, N, n_para, h, eps = 7, 129, 3, 20.0 / 128, 0.025
+    b0, _ = vortex_rhs(6)
+    b0 = b0.copy()
+    b0[0] = b0[-1] = 0
+    b0[:, 0] = b0[:, -1] = 0
+    scales = [1.0, 1e-3, 30.0, 0.2, 4.0, 1e-6, 1.0]
+    bs = np.stack([sc * np.roll(b0, 5 * k, axis=1) for k, sc in enumerate(scales)])
+    bs[:, :, 0] = bs[:, :, -1] = 0
+    bs[6, 40, 40] = np.nan
+    refs = []
+    for k in range(B):
+        ref = oracle.GlobalSolver(N, N, n_para, h, eps)
+        ref.b[:] = bs[k]
+        refs.append(ref)
+    eng = SlabMultigrid(N, N, n_para, h, eps, world=1, rank=0, batch=B, batch_stop="each", use_graph=graph)
+    eng.set_b_rows(torch.from_numpy(bs).cuda())
+    for rnd in range(2):
+        if rnd == 1:  # the reference driver's change of the right-hand side between solves (test/test.py:77-78); x stays
+            for ref in refs:
+                ref.b[1:-1] += ref.b[0:-2].copy()
+                ref.b[:] /= 2
+            eng.set_b_rows(torch.from_numpy(np.stack([ref.b for ref in refs])).cuda())
+        want = [ref.solve() for ref in refs]
+        err = eng.solve()
+        its = [ref.it for ref in refs]
+        assert eng.problem_its.tolist() == its, (rnd, eng.problem_its, its)
+        assert len(set(its)) >= (4 if rnd == 0 else 2)  # the batch does hold problems that stop at different cycles
+        for k in range(B - 1):
+            assert eng.problem_errs[k] == want[k], (rnd, k)
+            assert np.array_equal(_rows(eng, eng.x0)[k], refs[k].x), (rnd, k)
+            assert np.array_equal(_rows(eng, eng.r0)[k], refs[k].r), (rnd, k)
+        assert np.isnan(eng.problem_errs[6]) and np.isnan(want[6]) and eng.problem_its[6] == 1 and np.isnan(err)
+        assert eng.it == max(its)
+    # the default rule looks at the maximum over the batch: all problems run as long as the slowest
+    eng2 = SlabMultigrid(N, N, n_para, h, eps, world=1, rank=0, batch=B - 1, use_graph=graph)
+    eng2.set_b_rows(torch.from_numpy(bs[: B - 1]).cuda())
+    eng2.solve()
+    assert eng2.it == max(ref.it for ref in [oracle_first_solve(bs[k], N, n_para, h, eps) for k in range(B - 1)])
+    eng.close()
+    eng2.close()
+
+
+def oracle_first_solve(b, N, n_para, h, eps):
+    ref = oracle.GlobalSolver(N, N, n_para, h, eps)
+    ref.b[:] = b
+    ref.solve()
+    return ref
+
+
 def test_fix_coarse_ascent_equals_oracle():
     gny = gnx = 257
     b = _rhs(gny, gnx, 3)

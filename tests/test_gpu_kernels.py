@@ -578,7 +578,7 @@ def _fused_restriction_case(L, C, torch, shape, sweeps, mode, store_r, om):
     o2, r2, cb2 = padded(x), padded(z), padded(zc)
     s2 = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
     L.check(lib.mg_smooth_fused_restrict(*args, o2.data_ptr(), r2.data_ptr() if store_r else None, *cargs, h, om, s2.data_ptr(),
-                                         cb2.data_ptr(), cny, cnx, cb2.stride(0), 2, cny - 1, 1, 0, 0, 0, st))
+                                         0, cb2.data_ptr(), cny, cnx, cb2.stride(0), 2, cny - 1, 1, 0, 0, 0, st))
     assert np.array_equal(o2.cpu().numpy(), o1.cpu().numpy())
     assert np.array_equal(cb2.cpu().numpy(), cb1.cpu().numpy())
     n1, n2 = C.c_double(), C.c_double()
@@ -645,7 +645,7 @@ def test_fused_presmoothing_recomputed(L, shape, resid, om):
     o1, cb1, cb2 = padded(z), padded(zc), padded(zc)
     for xo, cb in ((o1, cb1), (None, cb2)):
         L.check(lib.mg_smooth_fused_restrict(db.data_ptr(), None, xo.data_ptr() if xo is not None else None, None, None, ny,
-                                             nx, ld, 0, 0, 0, j0, j1, flo, fhi, -1, 3, h, om, None, cb.data_ptr(), cny, cnx,
+                                             nx, ld, 0, 0, 0, j0, j1, flo, fhi, -1, 3, h, om, None, 0, cb.data_ptr(), cny, cnx,
                                              cb.stride(0), 2, cny - 1, 1, 0, 0, 0, st))
     assert np.array_equal(cb1.cpu().numpy(), cb2.cpu().numpy())
     assert cb1.cpu().numpy().any()

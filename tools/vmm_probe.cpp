@@ -33,7 +33,7 @@ static float time_out(double *xout)
     CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         if (mg_smooth_fused_restrict(b, xin, xout, nullptr, crs, N, N, LD, CN, CN, CLD, 1, N - 1, 0, N - 1, 0, 6, 20.0 / 32768, 1.0,
-                                     nrm_slots, crs_b, CN, CN, CLD, 1, CN - 1, 1, 0, 0, 0, st)) {
+                                     nrm_slots, 0, crs_b, CN, CN, CLD, 1, CN - 1, 1, 0, 0, 0, st)) {
             printf("launch failed: %s\n", mg_last_error());
             exit(1);
         }
