@@ -46,6 +46,10 @@ const char *mg_last_error(void);
  *   "fused_waves" 1 | 2 | 4  column strips (waves) per workgroup of the fused passes
  *   "fused_min_rows" 4..128  shortest tile (rows) the fused passes choose on levels too small to fill the chip
  *   "fused_min_blocks" n     ... tiles are halved while a launch has fewer workgroups than this
+ *   "fused_lockstep" n       the waves of a workgroup of the fused passes (neighbouring strips of the same rows) meet at
+ *                            a barrier every n groups of six rows, which keeps them on the same DRAM pages (default 1;
+ *                            0 = never)
+ *   "fused_rows"     n       rows per tile of the fused passes (0 = automatic), as mg_set_fused_tuning's second argument
  *   "xcd_stagger"    n       column blocks by which the bands of consecutive XCDs are shifted (-1: an eighth of the
  *                            width, 0 = off, the default: no effect was measured)
  *   "stream_min_mib"  n      arrays of at least n MiB are written with streaming (non-temporal) stores, which keeps

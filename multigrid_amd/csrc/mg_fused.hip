@@ -33,6 +33,7 @@ int g_fused_rows = 0;
 int g_fused_min_rows = 8;
 int g_fused_min_blocks = 2048;
 int g_xcd_stagger = 0;
+int g_fused_lockstep = 1; // measured at 32769 x 32769: finest pass 5.57 -> 5.50 ms, 9-stage pass 4.23 -> 4.12 ms
 
 extern "C" int mg_set_fused_tuning(int unroll, int rows)
 {
@@ -118,7 +119,7 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
     a.ny = ny, a.nx = nx, a.ld = ld, a.cny = cny, a.cnx = cnx, a.cld = cld;
     a.j0 = j0, a.j1 = j1, a.flo = fix_lo, a.fhi = fix_hi, a.oj = (int)ofst_j;
     a.h2 = h * h, a.hh = 1 / (h * h), a.om = omega, a.norm = (u64 *)norm_slots, a.norm_stride = norm_stride;
-    a.rpb = a.ncb = a.nrc = a.ntc = a.stagger = 0;
+    a.rpb = a.ncb = a.nrc = a.ntc = a.stagger = a.lockstep = 0;
     a.cb = coarse_b, a.cbnx = cbnx, a.cbld = cbld, a.T0 = T0, a.T1 = T1;
     a.nbatch = nbatch, a.bstride = bstride, a.cstride = cstride, a.cbstride = cbstride;
     // streaming stores when what the pass writes dwarfs the caches: x (and r), or the coarse right-hand side alone

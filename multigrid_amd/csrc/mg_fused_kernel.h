@@ -16,6 +16,7 @@ struct FusedArgs {
     i64 j0, j1;          // rows to produce
     i64 flo, fhi;        // rows <= flo and >= fhi are fixed (Dirichlet): passed through
     int rpb, ncb, nrc, ntc, oj, stagger;
+    int lockstep;        // > 0: the waves of a workgroup meet at a barrier every `lockstep` groups of six rows
     double h2, hh;
     double om; // damped Jacobi: x + om * (t - x), t the undamped value (DAMPED instantiations only)
     u64 *norm;
@@ -498,6 +499,8 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                 }
             };
             int i = ia;
+            const int lockstep = a.lockstep;
+            int since = 0;
             auto next_group = [&]() { // the oldest group of the b ring becomes the youngest
                 if constexpr (BL) {
                     double *const t = G[NG - 1];
@@ -515,6 +518,12 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                 step(int_c<4>{}, i + 4);
                 step(int_c<5>{}, i + 5);
                 next_group();
+                // lockstep: the waves of the workgroup (neighbouring strips of the same rows) meet every `lockstep`
+                // groups of six rows, so that they keep touching the same DRAM pages at about the same time
+                if (lockstep && ++since == lockstep) {
+                    since = 0;
+                    __builtin_amdgcn_s_barrier();
+                }
             }
             if (i < i1) step(int_c<0>{}, i);
             if (i + 1 < i1) step(int_c<1>{}, i + 1);
@@ -533,6 +542,16 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
         else
             run(std::false_type{});
         if (U == 1 && !st[0]) nmax = 0; // only the owned columns count towards the norm
+    } else if (a.lockstep && rb < re) {
+        // a wave without a strip of its own (the last workgroup of a row of tiles) keeps its siblings' appointments
+        const int i0 = rb - DC, i1 = re + DC;
+        const int ia = PROLONG ? i0 - ((i0 - PS - a.oj) & 1) : i0;
+        int since = 0;
+        for (int i = ia; i + 6 <= i1; i += 6)
+            if (++since == a.lockstep) {
+                since = 0;
+                __builtin_amdgcn_s_barrier();
+            }
     }
     if constexpr (RESID) {
         if (a.norm) { // uniform
@@ -555,6 +574,7 @@ extern int g_fused_unroll; // column pairs per lane of the shallow passes
 extern int g_fused_rows;   // rows per tile, 0 = automatic
 extern int g_fused_min_rows; // shortest tile the automatic choice goes down to on small levels
 extern int g_fused_min_blocks; // ... as long as the launch has fewer workgroups than this
+extern int g_fused_lockstep; // barrier among the waves of a workgroup every so many groups of six rows (0 = never)
 extern int g_xcd_stagger;    // column blocks by which consecutive XCD bands are shifted; -1 = an eighth of the width
 
 template <int K, bool PROLONG, bool ZERO, bool RESID, bool RESTRICT, int U, int PS = 0, bool DAMPED = false>
@@ -579,6 +599,7 @@ int launch_fused(FusedArgs a, hipStream_t st)
     }
     a.rpb = rpb;
     a.stagger = g_xcd_stagger < 0 ? a.ncb / 8 : g_xcd_stagger;
+    a.lockstep = g_fused_lockstep;
     a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
     const dim3 grid((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), block(64 * wpb);
     const size_t lds = DK >= 5 ? (size_t)wpb * ((DK + 1) / 3 + 1) * 3 * W * sizeof(double) : 0;

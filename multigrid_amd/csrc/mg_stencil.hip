@@ -231,6 +231,8 @@ extern int g_fused_waves;     // mg_fused.hip
 extern int g_fused_min_rows;  // mg_fused.hip
 extern int g_fused_min_blocks; // mg_fused.hip
 extern int g_xcd_stagger;      // mg_fused.hip
+extern int g_fused_lockstep;   // mg_fused.hip
+extern int g_fused_rows;       // mg_fused.hip
 
 extern "C" int mg_set_tuning(const char *key, int value)
 {
@@ -255,6 +257,12 @@ extern "C" int mg_set_tuning(const char *key, int value)
     } else if (!strcmp(key, "fused_min_blocks")) {
         MG_REQUIRE(value >= 1 && value <= (1 << 20), "mg_set_tuning: fused_min_blocks must be 1..2^20");
         g_fused_min_blocks = value;
+    } else if (!strcmp(key, "fused_rows")) {
+        MG_REQUIRE(value >= 0 && value <= 8192, "mg_set_tuning: fused_rows must be 0..8192");
+        g_fused_rows = value;
+    } else if (!strcmp(key, "fused_lockstep")) {
+        MG_REQUIRE(value >= 0 && value <= 1024, "mg_set_tuning: fused_lockstep must be 0..1024");
+        g_fused_lockstep = value;
     } else if (!strcmp(key, "xcd_stagger")) {
         MG_REQUIRE(value >= -1 && value <= (1 << 20), "mg_set_tuning: xcd_stagger must be -1 (an eighth of the width) or >= 0");
         g_xcd_stagger = value;

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--exp", type=int, default=14)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--cycles", type=int, default=10)
+    ap.add_argument("--also", nargs="*", default=[], help="key=value settings held fixed for the whole run")
     args = ap.parse_args()
     import torch
     import bench
@@ -27,6 +28,9 @@ def main():
     eng = SlabMultigrid(N, N, max(1, n - 4), 20.0 / 2 ** (n + 1), 0.0, world=1, rank=0, eager_dead_levels=True, tune_placement=True)
     bench.fill_rhs(eng, torch, n, 0)
     eng.presmooth()
+    for kv in args.also:
+        k, v = kv.split("=")
+        check(eng.ops.L.mg_set_tuning(k.encode(), int(v)))
     for rnd in range(args.rounds):
         for v in args.values:
             check(eng.ops.L.mg_set_tuning(args.knob.encode(), v))

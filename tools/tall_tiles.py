@@ -38,14 +38,17 @@ def main():
 
     rows_list = [int(v) for v in sys.argv[1:]] or [0, 64, 128, 256, 512, 1024, 2048, 2731, 4096, 5462]
     for rows in rows_list:
-        check(ops.L.mg_set_fused_tuning(1, rows))
-        fin = t(lambda: ops.smooth_fused(b, xa, xb, None, crs, L.nx, Lc.nx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, 6, L.h, norm,
-                                         cb, Lc.nx, Lc.t0, Lc.t1))
-        asc = t(lambda: ops.smooth_fused(b, None, xb, None, crs, L.nx, Lc.nx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, 9, L.h, None,
-                                         prolong_after=3))
-        des = t(lambda: ops.smooth_fused(b, None, None, None, None, L.nx, Lc.nx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, 3, L.h, None,
-                                         cb, Lc.nx, Lc.t0, Lc.t1))
-        print(f"rows per tile {rows:5d}: finest pass {fin:.3f} ms, 9-stage ascent {asc:.3f} ms, descent without x {des:.3f} ms", flush=True)
+        for lock in [int(v) for v in os.environ.get("LOCKSTEP", "0").split(",")]:
+            check(ops.L.mg_set_tuning(b"fused_lockstep", lock))
+            check(ops.L.mg_set_fused_tuning(1, rows))
+            fin = t(lambda: ops.smooth_fused(b, xa, xb, None, crs, L.nx, Lc.nx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, 6, L.h, norm,
+                                             cb, Lc.nx, Lc.t0, Lc.t1))
+            asc = t(lambda: ops.smooth_fused(b, None, xb, None, crs, L.nx, Lc.nx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, 9, L.h, None,
+                                             prolong_after=3))
+            des = t(lambda: ops.smooth_fused(b, None, None, None, None, L.nx, Lc.nx, L.t0, L.t1, L.fix_lo, L.fix_hi, L.oj, 3, L.h, None,
+                                             cb, Lc.nx, Lc.t0, Lc.t1))
+            print(f"rows per tile {rows:5d}, lockstep {lock}: finest pass {fin:.3f} ms, 9-stage ascent {asc:.3f} ms, "
+                  f"descent without x {des:.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
