@@ -208,6 +208,16 @@ int mg_sor(const double *b, double *x, double *r, int64_t ny, int64_t nx, int64_
            int64_t iterations, int backward, int ordering, int64_t nbatch, int64_t bstride, void *stream);
 
 /*
+ * One colour of a red-black Gauss-Seidel sweep, in place, rows j0 <= j < j1 (1 <= j0, j1 <= ny-1): the interior cells
+ * with (j + i) % 2 == colour take the value of mg_jacobi's expression computed from the current array.  A sweep is
+ * colour 0 followed by colour 1.  No counterpart in the reference (it smooths the fine levels with Jacobi,
+ * core/numba_modules.py:53-66): a smoother option of this build, which unlike undamped Jacobi damps the checkerboard
+ * mode of the error.
+ */
+int mg_gauss_seidel_rb(const double *b, double *x, int64_t ny, int64_t nx, int64_t ld, int64_t j0, int64_t j1, double h,
+                       int colour, int64_t nbatch, int64_t bstride, void *stream);
+
+/*
  * dst[0:ny, 0:nx] = src[0:ny, 0:nx] with independent leading dimensions.  The data movement of
  * split (core/numba_modules.py:10-20) and of the stitch in gather_blocks
  * (core/parallel_multigrid.py:135-138): the caller offsets the pointers to select the block.

@@ -47,6 +47,7 @@ SIGNATURES = {
                                   _i, _i, _i, _i, _i, _i, _i, _p], _n),
     "mg_set_fused_tuning": ([_n, _n], _n),
     "mg_sor": ([_p, _p, _p, _i, _i, _i, _d, _i, _n, _n, _i, _i, _p], _n),
+    "mg_gauss_seidel_rb": ([_p, _p, _i, _i, _i, _i, _i, _d, _n, _i, _i, _p], _n),
     "mg_copy2d": ([_p, _i, _p, _i, _i, _i, _p], _n),
     "mg_block_exchange": ([_p, _i, _i, _i, _p, _p], _n),
     "mg_block_exchange_static": ([_p, _i, _i, _i, _p], _n),

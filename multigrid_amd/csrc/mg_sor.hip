@@ -312,19 +312,45 @@ __global__ __launch_bounds__(256) void mg_sor_wave_kernel(const double *__restri
         }
 }
 
-__global__ __launch_bounds__(256) void mg_sor_rb_kernel(const double *__restrict__ b, double *x, i64 ny, i64 nx, i64 ld,
+// One colour of a red-black sweep over rows j0 <= j < j1.  GS: plain Gauss-Seidel, the Jacobi value in place;
+// otherwise SOR with omega = 1.5 (the coarse smoother's weight).
+template <bool GS>
+__global__ __launch_bounds__(256) void mg_sor_rb_kernel(const double *__restrict__ b, double *x, i64 j0, i64 j1, i64 nx, i64 ld,
                                                         double h2, int colour, i64 bstride)
 {
     b += (i64)blockIdx.z * bstride;
     x += (i64)blockIdx.z * bstride;
     const double a = 1.5, alpha = 1 - a, beta = a / 4;
-    for (i64 j = 1 + blockIdx.y; j <= ny - 2; j += gridDim.y) {
+    for (i64 j = j0 + blockIdx.y; j < j1; j += gridDim.y) {
         const i64 i0 = 1 + ((colour + j + 1) & 1);
         for (i64 i = i0 + 2 * ((i64)blockIdx.x * 256 + threadIdx.x); i <= nx - 2; i += 2 * (i64)gridDim.x * 256) {
             double *p = x + j * ld + i;
-            *p = alpha * *p + beta * (p[1] + p[-1] + p[ld] + p[-ld] - h2 * b[j * ld + i]);
+            if constexpr (GS)
+                *p = 0.25 * (p[1] + p[-1] + p[ld] + p[-ld] - h2 * b[j * ld + i]);
+            else
+                *p = alpha * *p + beta * (p[1] + p[-1] + p[ld] + p[-ld] - h2 * b[j * ld + i]);
         }
     }
+}
+
+extern "C" int mg_gauss_seidel_rb(const double *b, double *x, i64 ny, i64 nx, i64 ld, i64 j0, i64 j1, double h, int colour,
+                                  i64 nbatch, i64 bstride, void *stream)
+{
+    MG_REQUIRE(b && x, "mg_gauss_seidel_rb: null array");
+    MG_REQUIRE(ny >= 3 && nx >= 3 && ld >= nx, "mg_gauss_seidel_rb: bad shape %lld x %lld (ld %lld)", (long long)ny, (long long)nx,
+               (long long)ld);
+    MG_REQUIRE(j0 >= 1 && j1 <= ny - 1 && j0 <= j1, "mg_gauss_seidel_rb: row range [%lld, %lld) outside the interior", (long long)j0,
+               (long long)j1);
+    MG_REQUIRE(colour == 0 || colour == 1, "mg_gauss_seidel_rb: colour must be 0 or 1");
+    MG_REQUIRE(nbatch >= 1 && nbatch <= 65535 && (nbatch == 1 || bstride >= ny * ld), "mg_gauss_seidel_rb: bad batch");
+    if (j0 == j1) return 0;
+    unsigned gx = (unsigned)(((nx - 2 + 1) / 2 + 255) / 256);
+    if (gx > 64) gx = 64;
+    const unsigned gy = (unsigned)(j1 - j0 < 4096 ? j1 - j0 : 4096);
+    hipLaunchKernelGGL(mg_sor_rb_kernel<true>, dim3(gx, gy, (unsigned)nbatch), dim3(256), 0, (hipStream_t)stream, b, x, j0, j1, nx, ld,
+                       h * h, colour, bstride);
+    MG_LAUNCH_CHECK("mg_gauss_seidel_rb");
+    return 0;
 }
 
 // The LDS limit of a kernel is an attribute of the function PER DEVICE: it is set once on every device a launch is
@@ -410,7 +436,7 @@ extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64
         for (i64 it = 0; it < iterations; ++it)
             for (int p = 0; p < (backward ? 4 : 2); ++p) {
                 const int colour = (p == 0 || p == 3) ? 0 : 1;
-                hipLaunchKernelGGL(mg_sor_rb_kernel, grid, dim3(256), 0, st, b, x, ny, nx, ld, h2, colour, bstride);
+                hipLaunchKernelGGL(mg_sor_rb_kernel<false>, grid, dim3(256), 0, st, b, x, (i64)1, ny - 1, nx, ld, h2, colour, bstride);
                 MG_LAUNCH_CHECK("mg_sor (red-black)");
             }
     }

@@ -49,7 +49,7 @@ class SlabMultigrid:
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
                  store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
                  recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=False,
-                 overlap_min_rows=4096, batch_stop="max"):
+                 overlap_min_rows=4096, batch_stop="max", fine_smoother="jacobi"):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -59,6 +59,16 @@ class SlabMultigrid:
             world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
             rank = dist.get_rank(group) if world > 1 else 0
         self.world, self.rank = world, rank
+        # fine_smoother: "jacobi" = the reference's sweep on the Jacobi levels; "redblack" = red-black Gauss-Seidel
+        # sweeps in their place (same counts n1/n2; damps the checkerboard mode that undamped Jacobi leaves alone).
+        # One kernel per colour and operation, one rank: the fused passes are Jacobi pipelines.
+        if fine_smoother not in ("jacobi", "redblack"):
+            raise ValueError("fine_smoother must be 'jacobi' or 'redblack'")
+        if fine_smoother == "redblack":
+            if world != 1:
+                raise ValueError("fine_smoother='redblack' runs on one rank")
+            fused = False
+        self.fine_smoother = fine_smoother
         self.fused = fused and getattr(ops, "supports_fused", False)
         if halo is None and world > 1:
             # fused: as deep as the deepest pass (6 sweeps + residual + restriction = 8; the 9-sweep pass of
@@ -537,6 +547,22 @@ class SlabMultigrid:
                 src = dst
             if restrict:
                 after_restriction()
+            return src
+        if self.fine_smoother == "redblack":  # in place: no second array
+            if src is None:
+                src = xa
+                o.zero_(src)
+            elif crs is not None:
+                o.prolong_add(crs, cnx, src, L.nx, L.t0, L.t1, 0, L.oj)
+            for _ in range(n):
+                o.gauss_seidel_rb(self.b[l], src, L.nx, L.t0, L.t1, L.h)
+            if r is not None:
+                if norm is not None:
+                    o.norm_reset(norm)
+                o.residual(r, src, self.b[l], L.nx, L.t0, L.t1, L.h, norm, finest)
+            if restrict:
+                assert r is self.r[l]
+                o.restrict(self.r[l], L.nx, cb, Lc.nx, Lc.t0, Lc.t1, 0, L.oj)
             return src
         # one kernel per operation, one single-row exchange per sweep
         if src is None:

@@ -45,6 +45,8 @@ def lib():
         L.orc_smooth_sweep_jacobi.argtypes = [_d, _dw, _dw, _i64, _i64, C.c_double]
         L.orc_smooth_sweep_jacobi_damped.argtypes = [_d, _dw, _dw, _i64, _i64, C.c_double, C.c_double]
         L.orc_global_set_jacobi_omega.argtypes = [C.c_void_p, C.c_double]
+        L.orc_global_set_fine_smoother.argtypes = [C.c_void_p, C.c_int]
+        L.orc_smooth_sweep_rbgs.argtypes = [_d, _dw, _i64, _i64, C.c_double]
         for f in (L.orc_smooth, L.orc_smooth_altern, L.orc_smooth_altern_rb):
             f.argtypes = [_d, _dw, C.c_double, _dw, _i64, _i64, _i64]
         L.orc_coarse.argtypes = [_d, _i64, _i64, _dw, _i64, _i64, _i64, _i64]
@@ -99,6 +101,11 @@ def smooth_sweep_jacobi(b, a, a_temp, h, omega=1.0):
         lib().orc_smooth_sweep_jacobi(b, a, a_temp, a.shape[0], a.shape[1], h)
     else:
         lib().orc_smooth_sweep_jacobi_damped(b, a, a_temp, a.shape[0], a.shape[1], h, omega)
+
+
+def smooth_sweep_rbgs(b, a, h):
+    """One red-black Gauss-Seidel sweep in place (an option of this build; not a reference function)."""
+    lib().orc_smooth_sweep_rbgs(b, a, a.shape[0], a.shape[1], h)
 
 
 def smooth(b, x, h, r, iterations):
@@ -201,12 +208,14 @@ class BlockSolver:
 class GlobalSolver:
     """The reference V-cycle on the undecomposed (ny x nx) grid, boundary included."""
 
-    def __init__(self, ny, nx, n_para, h0, eps, ordering="lexicographic", fix_coarse_ascent=False, jacobi_omega=1.0):
+    def __init__(self, ny, nx, n_para, h0, eps, ordering="lexicographic", fix_coarse_ascent=False, jacobi_omega=1.0,
+                 fine_smoother="jacobi"):
         o = {"lexicographic": 0, "redblack": 1}[ordering]
         self._h = lib().orc_global_create(ny, nx, n_para, h0, eps, o, int(fix_coarse_ascent))
         if not self._h:
             raise ValueError("grid sides minus one must be divisible by 2**n_para, with >= 2 cells left")
         lib().orc_global_set_jacobi_omega(self._h, jacobi_omega)
+        lib().orc_global_set_fine_smoother(self._h, {"jacobi": 0, "redblack": 1}[fine_smoother])
         self.n_para = n_para
         self.nwl = lib().orc_global_num_whole_levels(self._h)
         self.x, self.b, self.r = (self.array(k, 0) for k in ("x", "b", "r"))

@@ -136,6 +136,24 @@ void orc_smooth_sweep_jacobi_damped(const double *b, double *a, double *a_temp, 
             a[j * nx + i] = a_temp[j * nx + i];
 }
 
+/*
+ * One red-black Gauss-Seidel sweep (an option of this build for the fine levels; the reference smooths them with
+ * Jacobi): the cells with even j + i take the Jacobi value of smooth_sweep_jacobi (numba_modules.py:61-63, same
+ * expression) computed from the current array, in place, then the cells with odd j + i do.  Cells of one colour
+ * do not depend on each other, so the order inside a colour does not matter.
+ */
+void orc_smooth_sweep_rbgs(const double *b, double *a, i64 ny, i64 nx, double h)
+{
+    double h2 = h * h;
+    for (int colour = 0; colour < 2; colour++) {
+#pragma omp parallel for schedule(static) if (ny * nx >= ORC_PAR_MIN)
+        for (i64 j = 1; j < ny - 1; j++)
+            for (i64 i = 1 + ((colour + j + 1) & 1); i < nx - 1; i += 2)
+                a[j * nx + i] = 0.25 * (a[j * nx + i + 1] + a[j * nx + i - 1] + a[(j + 1) * nx + i] + a[(j - 1) * nx + i] -
+                                        h2 * b[j * nx + i]);
+    }
+}
+
 static inline void sor_point(const double *b, double *x, i64 nx, i64 j, i64 i, double alpha, double beta,
                              double h2)
 {
@@ -561,6 +579,7 @@ typedef struct {
     double eps;
     int ordering;          /* 0 lexicographic (reference), 1 red-black */
     double jacobi_omega;   /* 1 = the reference's sweep */
+    int fine_smoother;     /* 0 Jacobi (reference), 1 red-black Gauss-Seidel */
     int fix_coarse_ascent; /* 0: reference loop bounds (:302); 1: the ascent also reaches xw[0] */
     int max_cycles;
     int it;
@@ -620,6 +639,7 @@ void orc_global_destroy(void *hd)
 
 void orc_global_set_max_cycles(void *hd, int m) { ((global_t *)hd)->max_cycles = m; }
 void orc_global_set_jacobi_omega(void *hd, double omega) { ((global_t *)hd)->jacobi_omega = omega; }
+void orc_global_set_fine_smoother(void *hd, int kind) { ((global_t *)hd)->fine_smoother = kind; }
 int orc_global_num_whole_levels(void *hd) { return ((global_t *)hd)->nwl; }
 
 /* which: 0 x, 1 b, 2 r (Jacobi levels); 3 xw, 4 bw, 5 rw (coarse-smoother levels) */
@@ -643,7 +663,9 @@ static void g_smooth(global_t *s, const double *b, double *x, double h, double *
 {
     memcpy(s->tmp, x, (size_t)(ny * nx) * sizeof(double));
     for (int k = 0; k < iterations; k++) {
-        if (s->jacobi_omega == 1.0)
+        if (s->fine_smoother == 1)
+            orc_smooth_sweep_rbgs(b, x, ny, nx, h);
+        else if (s->jacobi_omega == 1.0)
             orc_smooth_sweep_jacobi(b, x, s->tmp, ny, nx, h);
         else
             orc_smooth_sweep_jacobi_damped(b, x, s->tmp, ny, nx, h, s->jacobi_omega);

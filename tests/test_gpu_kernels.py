@@ -654,3 +654,31 @@ def test_fused_presmoothing_recomputed(L, shape, resid, om):
                                j0, j1, flo, fhi, -1, 6, 3, h, om, None, 1, 0, 0, st) != 0
     assert lib.mg_smooth_fused(db.data_ptr(), out.data_ptr(), rr.data_ptr(), None, dc.data_ptr(), ny, nx, ld, cny, cnx,
                                dc.stride(0), j0, j1, flo, fhi, -1, 9, 3, h, om, None, 1, 0, 0, st) != 0
+
+
+@pytest.mark.parametrize("shape", [(3, 3), (5, 9), (33, 33), (130, 130), (257, 513), (100, 2051)], ids=str)
+def test_gauss_seidel_redblack_vs_oracle(shape):
+    """mg_gauss_seidel_rb (colour 0, then colour 1) == the oracle's red-black sweep, bit for bit; a row range leaves
+    the other rows alone."""
+    import torch
+    from multigrid_amd import _lib as L
+    lib = L.lib()
+    ny, nx = shape
+    rng = np.random.default_rng(3)
+    b, x = rng.standard_normal(shape), rng.standard_normal(shape)
+    want = x.copy()
+    oracle.smooth_sweep_rbgs(b, want, 0.3)
+    ld = (nx + 15) // 16 * 16
+    db = torch.zeros(ny, ld, dtype=torch.float64, device="cuda")
+    dx = torch.zeros(ny, ld, dtype=torch.float64, device="cuda")
+    db[:, :nx], dx[:, :nx] = torch.from_numpy(b).cuda(), torch.from_numpy(x).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for colour in (0, 1):
+        L.check(lib.mg_gauss_seidel_rb(db.data_ptr(), dx.data_ptr(), ny, nx, ld, 1, ny - 1, 0.3, colour, 1, 0, st))
+    assert np.array_equal(dx[:, :nx].cpu().numpy(), want)
+    if ny >= 33:
+        dx[:, :nx] = torch.from_numpy(x).cuda()
+        L.check(lib.mg_gauss_seidel_rb(db.data_ptr(), dx.data_ptr(), ny, nx, ld, 10, 20, 0.3, 0, 1, 0, st))
+        got = dx[:, :nx].cpu().numpy()
+        assert np.array_equal(got[:10], x[:10]) and np.array_equal(got[20:], x[20:]) and not np.array_equal(got[10:20], x[10:20])
+    assert lib.mg_gauss_seidel_rb(db.data_ptr(), dx.data_ptr(), ny, nx, ld, 0, ny, 0.3, 0, 1, 0, st) != 0

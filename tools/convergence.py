@@ -8,6 +8,8 @@ test/test.py:40-58) and each tolerance, solve() is run from x = 0 with
   * fix_coarse_ascent=True (the textbook ascent through every whole-domain level),
   * the same with damped Jacobi sweeps (jacobi_omega=0.8; the reference's undamped sweep leaves the
     checkerboard mode of the error untouched, which is the floor max|r| stalls at),
+  * the same with red-black Gauss-Seidel sweeps on the fine levels (fine_smoother="redblack": one kernel per
+    colour and operation, no fused passes, so fewer cycles but several times the traffic per cycle),
 for several numbers of Jacobi levels, and one line is printed per run: V-cycles, whether the
 stop rule ended on the tolerance, final max|r|, wall time of the solve, algorithmic bytes moved
 (cycles x levels.algorithmic_bytes_per_cycle) and max|r| reduction per cycle (geometric mean).
@@ -34,15 +36,16 @@ def main():
     from multigrid_amd.engine import SlabMultigrid
     from multigrid_amd.levels import algorithmic_bytes_per_cycle
 
-    print(f"{'n':>3}{'n_para':>7}{'schedule':>11}{'eps':>9}{'cycles':>7}{'stop':>10}{'max|r|':>10}{'ms':>9}"
+    print(f"{'n':>3}{'n_para':>7}{'schedule':>12}{'eps':>9}{'cycles':>7}{'stop':>10}{'max|r|':>10}{'ms':>9}"
           f"{'GB (algorithmic)':>18}{'reduction/cycle':>17}", flush=True)
     for n in args.exps:
         for n_para in sorted({max(2, n - 8), n - 6, n - 4}):
             if n_para < 1 or n_para >= n:
                 continue
-            for name, fix, om in (("reference", False, 1.0), ("textbook", True, 1.0), ("tb+damped", True, 0.8)):
+            for name, fix, om, sm in (("reference", False, 1.0, "jacobi"), ("textbook", True, 1.0, "jacobi"),
+                                      ("tb+damped", True, 0.8, "jacobi"), ("tb+redblack", True, 1.0, "redblack")):
                 eng = SlabMultigrid(2 ** (n + 1) + 1, 2 ** (n + 1) + 1, n_para, 20.0 / 2 ** (n + 1), 0.0,
-                                    fix_coarse_ascent=fix, eager_dead_levels=True, jacobi_omega=om)
+                                    fix_coarse_ascent=fix, eager_dead_levels=True, jacobi_omega=om, fine_smoother=sm)
                 fill_rhs(eng, torch, n, 0)
                 gb = algorithmic_bytes_per_cycle(eng.plan) / 1e9
                 for eps in args.eps:
@@ -58,7 +61,7 @@ def main():
                     hist = eng.err_history
                     red = (hist[-1] / hist[0]) ** (1.0 / max(1, len(hist) - 1)) if len(hist) > 1 and hist[0] > 0 else float("nan")
                     stop = "eps" if err <= eps else ("diverged" if eng.diverged else "cap")
-                    print(f"{n:>3}{n_para:>7}{name:>11}{eps:>9.1e}{eng.it:>7}{stop:>10}{err:>10.2e}"
+                    print(f"{n:>3}{n_para:>7}{name:>12}{eps:>9.1e}{eng.it:>7}{stop:>10}{err:>10.2e}"
                           f"{ms:>9.2f}{gb * eng.it:>18.1f}{red:>17.3f}", flush=True)
                 eng.close()
                 del eng
