@@ -555,7 +555,7 @@ class SlabMultigrid:
             elif crs is not None:
                 o.prolong_add(crs, cnx, src, L.nx, L.t0, L.t1, 0, L.oj)
             for _ in range(n):
-                o.gauss_seidel_rb(self.b[l], src, L.nx, L.t0, L.t1, L.h)
+                o.gauss_seidel_rb(self.b[l], src, L.nx, L.t0, L.t1, L.h, row_offset=L.halo)
             if r is not None:
                 if norm is not None:
                     o.norm_reset(norm)
