@@ -33,6 +33,7 @@ int g_fused_rows = 0;
 int g_fused_min_rows = 8;
 int g_fused_min_blocks = 2048;
 int g_xcd_stagger = 0;
+int g_fused_rows_shallow = 32, g_fused_rows_deep = 128;
 int g_fused_lockstep = 1; // measured at 32769 x 32769: finest pass 5.57 -> 5.50 ms, 9-stage pass 4.23 -> 4.12 ms
 
 extern "C" int mg_set_fused_tuning(int unroll, int rows)

@@ -574,6 +574,7 @@ extern int g_fused_unroll; // column pairs per lane of the shallow passes
 extern int g_fused_rows;   // rows per tile, 0 = automatic
 extern int g_fused_min_rows; // shortest tile the automatic choice goes down to on small levels
 extern int g_fused_min_blocks; // ... as long as the launch has fewer workgroups than this
+extern int g_fused_rows_shallow, g_fused_rows_deep; // default tile heights of the passes of depth <= 5 / >= 9
 extern int g_fused_lockstep; // barrier among the waves of a workgroup every so many groups of six rows (0 = never)
 extern int g_xcd_stagger;    // column blocks by which consecutive XCD bands are shifted; -1 = an eighth of the width
 
@@ -592,7 +593,7 @@ int launch_fused(FusedArgs a, hipStream_t st)
     if (rpb <= 0) {
         // measured at 32769 x 32769 (profiles/): 64-row tiles are as fast as or faster than taller ones at
         // every depth, 32-row tiles faster still for the shallow from-zero pass
-        rpb = D <= 5 ? 32 : (D >= 9 ? 128 : 64); // the 9-sweep pass streams 9 extra rows per tile end: taller tiles
+        rpb = D <= 5 ? g_fused_rows_shallow : (D >= 9 ? g_fused_rows_deep : 64); // the 9-sweep pass streams 9 extra rows per tile end: taller tiles
         // a small level cannot fill the chip, and its pass lasts as long as one wave needs for one tile:
         // shorter tiles (down to g_fused_min_rows) cut that time; the extra overlap rows cost nothing there
         while (rpb > g_fused_min_rows && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) * a.nbatch < g_fused_min_blocks) rpb >>= 1;

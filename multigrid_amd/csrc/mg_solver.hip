@@ -299,13 +299,13 @@ int collect_err(mg_solver *s, int a, double *err)
 // the fast kind those become fin[] = {xa, xb, b, r}, in the assignment whose pass is fastest; all zero.  fin[]
 // and *cb_out stay null when the level is small (< 1 GiB per array), memory is short or anything fails: create
 // then allocates as usual.
-void place_finest(mg_solver *s, double *fin[4], double **cb_out)
+void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_out)
 {
     const int KMAX = 24;
     const i64 ny = s->gny, nx = s->gnx, ld = pitch(nx), n = ny * ld;
     const size_t bytes = (size_t)n * sizeof(double);
     for (int k = 0; k < 4; ++k) fin[k] = nullptr;
-    *cb_out = nullptr;
+    *cb_out = nullptr, *xa1_out = nullptr;
     size_t free_b = 0, total_b = 0;
     if (bytes < ((size_t)1 << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
     // room for the other levels (a third of the finest's four arrays, rounded up to two arrays) and a margin
@@ -381,6 +381,52 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out)
         ok = ok && hipMemsetAsync(cb, 0, cbytes, s->stream) == hipSuccess;
         if (ok) s->placement_candidates = nt, *cb_out = cb, cb = nullptr;
     }
+    // The same for the one other pass that writes gigabytes: level 1's ascent pass (1.04 or 1.10 ms at 32769 x 32769
+    // depending on the allocation it writes its x into), where that is the 9-stage pass with recomputed
+    // pre-smoothing.  Up to eight candidates are timed as its output beside the level's right-hand side (the array
+    // kept above); the fastest becomes the level's x.
+    if (ok && *cb_out && s->n_para >= 3) {
+        const i64 strips = (cnx + 107) / 108, blocks = ((strips + 3) / 4) * ((cny - 1 + 63) / 64);
+        const i64 c2ny = ((ny - 1) >> 2) + 1, c2nx = ((nx - 1) >> 2) + 1, c2ld = pitch(c2nx);
+        double *crs2 = nullptr, *cand[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        float t1[8], lo1 = 0, hi1 = 0;
+        int n1 = 0;
+        bool ok1 = cnx >= s->recompute_min_nx && blocks >= s->recompute_min_blocks &&
+                   hipMalloc((void **)&crs2, (size_t)(c2ny * c2ld) * sizeof(double)) == hipSuccess &&
+                   hipMemsetAsync(crs2, 0, (size_t)(c2ny * c2ld) * sizeof(double), s->stream) == hipSuccess;
+        while (ok1 && n1 < 8) {
+            if (hipMalloc((void **)&cand[n1], cbytes) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            ok1 = hipMemsetAsync(cand[n1], 0, cbytes, s->stream) == hipSuccess;
+            for (int rep = 0; rep < 3 && ok1; ++rep) {
+                ok1 = !mg_smooth_fused(*cb_out, nullptr, cand[n1], nullptr, crs2, cny, cnx, cld, c2ny, c2nx, c2ld, 1, cny - 1, 0, cny - 1,
+                                       0, N1 + N2, N1, 2 * s->h0, 1.0, nullptr, 1, 0, 0, s->stream);
+                if (rep == 0) ok1 = ok1 && hipEventRecord(e0, s->stream) == hipSuccess;
+            }
+            ok1 = ok1 && hipEventRecord(e1, s->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                  hipEventElapsedTime(&t1[n1], e0, e1) == hipSuccess;
+            if (!ok1) break;
+            ++n1;
+            lo1 = hi1 = t1[0];
+            int fast1 = 0;
+            for (int k = 1; k < n1; ++k) lo1 = t1[k] < lo1 ? t1[k] : lo1, hi1 = t1[k] > hi1 ? t1[k] : hi1;
+            for (int k = 0; k < n1; ++k) fast1 += t1[k] <= 1.01f * lo1;
+            if (n1 >= 3 && hi1 > 1.03f * lo1 && fast1 >= 2) break; // both kinds seen, and the fast one twice
+        }
+        if (ok1 && n1 > 0) {
+            int best = 0;
+            for (int k = 1; k < n1; ++k)
+                if (t1[k] < t1[best]) best = k;
+            if (hipMemsetAsync(cand[best], 0, cbytes, s->stream) == hipSuccess) *xa1_out = cand[best], cand[best] = nullptr;
+        }
+        if (!ok1) (void)hipGetLastError();
+        (void)hipStreamSynchronize(s->stream);
+        for (double *q : cand)
+            if (q) (void)hipFree(q);
+        if (crs2) (void)hipFree(crs2);
+    }
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (!ok) {
         (void)hipGetLastError();
@@ -449,12 +495,13 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
         }
         bool ok = true;
         double *fin[4] = {nullptr, nullptr, nullptr, nullptr};
-        double *cb1 = nullptr; // what the finest pass restricts into, when the placement selection made it
+        double *cb1 = nullptr, *xa1 = nullptr; // what the finest pass restricts into and level 1's x, when the placement selection made them
         if (flags & MG_SOLVER_TUNE_PLACEMENT) {
-            place_finest(s, fin, &cb1);
+            place_finest(s, fin, &cb1, &xa1);
             for (int k = 0; k < 4; ++k)
                 if (fin[k]) s->allocs.push_back(fin[k]);
             if (cb1) s->allocs.push_back(cb1);
+            if (xa1) s->allocs.push_back(xa1);
         }
         for (int l = 0; l < n_para && ok; ++l) {
             JLevel L;
@@ -464,7 +511,11 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
             if (l == 0 && fin[0]) { // placed (and left all zero) by place_finest
                 L.xa = fin[0], L.xb = fin[1], L.b = fin[2], L.r = fin[3];
             } else {
-                ok = !dev_alloc(s, &L.xa, L.ny * L.ld) && !dev_alloc(s, &L.xb, L.ny * L.ld);
+                if (l == 1 && xa1)
+                    L.xa = xa1;
+                else
+                    ok = !dev_alloc(s, &L.xa, L.ny * L.ld);
+                ok = ok && !dev_alloc(s, &L.xb, L.ny * L.ld);
                 if (ok && l == 1 && cb1)
                     L.b = cb1;
                 else

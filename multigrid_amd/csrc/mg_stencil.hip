@@ -233,6 +233,7 @@ extern int g_fused_min_blocks; // mg_fused.hip
 extern int g_xcd_stagger;      // mg_fused.hip
 extern int g_fused_lockstep;   // mg_fused.hip
 extern int g_fused_rows;       // mg_fused.hip
+extern int g_fused_rows_shallow, g_fused_rows_deep; // mg_fused.hip
 
 extern "C" int mg_set_tuning(const char *key, int value)
 {
@@ -260,6 +261,9 @@ extern "C" int mg_set_tuning(const char *key, int value)
     } else if (!strcmp(key, "fused_rows")) {
         MG_REQUIRE(value >= 0 && value <= 8192, "mg_set_tuning: fused_rows must be 0..8192");
         g_fused_rows = value;
+    } else if (!strcmp(key, "fused_rows_shallow") || !strcmp(key, "fused_rows_deep")) {
+        MG_REQUIRE(value >= 8 && value <= 1024, "mg_set_tuning: %s must be 8..1024", key);
+        (strcmp(key, "fused_rows_deep") ? g_fused_rows_shallow : g_fused_rows_deep) = value;
     } else if (!strcmp(key, "fused_lockstep")) {
         MG_REQUIRE(value >= 0 && value <= 1024, "mg_set_tuning: fused_lockstep must be 0..1024");
         g_fused_lockstep = value;

@@ -153,13 +153,13 @@ class SlabMultigrid:
         t0 = time.perf_counter()
         if tune_placement and batch is None and getattr(ops, "supports_placement", False) and self.fused:
             fin = self._place_finest(verbose=tune_placement == "verbose")
-        cb1 = None  # the array the finest pass restricts into, if the placement selection made it
+        cb1 = xa1 = None  # the array the finest pass restricts into and level 1's x, if the placement selection made them
         if fin is None:
             fin = [z(LV[0].ny, LV[0].ld) for _ in range(4)]
         else:
-            fin, cb1 = fin
+            fin, cb1, xa1 = fin
         slab1 = world > 1 and n_dist == 1  # the finest pass restricts into the slab that is then all-gathered
-        self._xa = [fin[0]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
+        self._xa = [fin[0]] + [xa1 if (l == 1 and xa1 is not None) else z(L.ny, L.ld) for l, L in enumerate(LV[:n_para]) if l >= 1]
         self._xb = [fin[1]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
         self.b = [fin[2]] + [cb1 if (l == 1 and cb1 is not None and not slab1) else z(L.ny, L.ld) for l, L in enumerate(LV) if l >= 1]
         self.r = [fin[3]] + [z(L.ny, L.ld) for L in LV[1:n_para]]
@@ -297,7 +297,46 @@ class SlabMultigrid:
         ops.stream.synchronize()
         self.placement = {"candidates": len(ms), "ms_as_output": [round(t, 3) for t in ms], "chosen": pick,
                           "both_kinds_seen": gap, "ms_chosen_combination": round(final, 3), "combinations_timed": combos}
-        return fin, cb
+        return fin, cb, self._place_level1(cb, ev, verbose)
+
+    def _place_level1(self, b1, ev, verbose=False):
+        """The same for the one other pass that writes gigabytes: level 1's ascent pass (its x, a quarter of the
+        finest array) takes 1.04 or 1.10 ms at 32769 x 32769 depending on the allocation it writes.  Up to eight
+        candidates are timed as its output (b = the level's right-hand side, which is kept); the fastest becomes the
+        level's x.  Only where that pass is the 9-stage one (recomputed pre-smoothing); None otherwise."""
+        if self.n_para < 3 or not self._recomputed(1) or (self.world > 1 and self.n_dist < 2):
+            return None
+        eng, ops, L1, L2 = self, self.ops, self.lv[1], self.lv[2]
+        crs = ops.zeros(L2.ny, L2.ld)
+        cands, ms = [], []
+        try:
+            for _ in range(8):
+                a = ops.zeros(L1.ny, L1.ld)
+                ops.begin()
+                for rep in range(3):
+                    ops.smooth_fused(b1, None, a, None, crs, L1.nx, L2.nx, L1.t0, L1.t1, L1.fix_lo, L1.fix_hi, L1.oj,
+                                     eng.N1 + eng.N2, L1.h, None, prolong_after=eng.N1, omega=eng.jacobi_omega)
+                    if rep == 0:
+                        ev[0].record(ops.stream)
+                ev[1].record(ops.stream)
+                ops.stream.synchronize()
+                cands.append(a)
+                ms.append(ev[0].elapsed_time(ev[1]) / 2)
+                if len(ms) >= 3 and max(ms) > 1.03 * min(ms) and sum(t <= 1.01 * min(ms) for t in ms) >= 2:
+                    break  # both kinds seen, and the fast one twice
+        except torch.OutOfMemoryError:
+            torch.cuda.empty_cache()
+        if not ms:
+            return None
+        k = min(range(len(ms)), key=lambda q: ms[q])
+        best = cands[k]
+        ops.zero_(best)
+        ops.stream.synchronize()
+        self.placement["level1_ms_as_output"] = [round(t, 4) for t in ms]
+        self.placement["level1_chosen"] = k
+        del cands, crs
+        torch.cuda.empty_cache()
+        return best
 
     # ------------------------------------------------------------------ data access
     @property
