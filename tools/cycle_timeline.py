@@ -3,7 +3,10 @@
 the previous finest pass, duration, name, grid.  Shows what runs beside what and where the stream idles.
 
     rocprofv3 --kernel-trace --output-format csv -d out -- python3 bench.py --no-cpu-baseline
-    python tools/cycle_timeline.py out/*/*_kernel_trace.csv [cycle index, default 8]
+    python tools/cycle_timeline.py out/*/*_kernel_trace.csv [index of the finest pass to start after]
+
+Without an index it takes the third last span between two finest passes that holds a whole cycle (more than
+20 kernels): the placement sampling and the untuned leg launch finest passes back to back, which are no cycles.
 """
 import csv
 import sys
@@ -11,7 +14,8 @@ import sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "mg_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 fin = [i for i, r in enumerate(rows) if "mg_fused_kernel<6, true, false, true, true" in r["Kernel_Name"]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+whole = [k for k in range(len(fin) - 1) if fin[k + 1] - fin[k] > 20]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else whole[-3]
 a, b = fin[k], fin[k + 1]
 t0 = int(rows[a]["End_Timestamp"])
 busy_end = t0
