@@ -50,6 +50,8 @@ const char *mg_last_error(void);
  *                            a barrier every n groups of six rows, which keeps them on the same DRAM pages (default 1;
  *                            0 = never)
  *   "fused_rows"     n       rows per tile of the fused passes (0 = automatic), as mg_set_fused_tuning's second argument
+ *   "fused_rows_shallow" n   the automatic tile height of passes of depth <= 5 (default 32) ...
+ *   "fused_rows_deep"    n   ... and of depth >= 9 (default 128); passes in between use 64 rows
  *   "xcd_stagger"    n       column blocks by which the bands of consecutive XCDs are shifted (-1: an eighth of the
  *                            width, 0 = off, the default: no effect was measured)
  *   "stream_min_mib"  n      arrays of at least n MiB are written with streaming (non-temporal) stores, which keeps

@@ -68,6 +68,76 @@ __global__ __launch_bounds__(256) void add_tile(const double* __restrict__ a, co
     *(double2*)(o + j * ld + c) = make_double2(x.x + y.x, x.y + y.y);
   }
 }
+// The byte mix of the fused finest pass without its arithmetic and without any overlap between tiles: per fine
+// point it reads x and b (16 B) and a quarter of a coarse value (2 B), writes x' (8 B) and a quarter of a coarse
+// value (2 B) = 28 B.  Same shape of access: a wave owns a strip of 128 columns (one 16-byte pair per lane) and
+// marches down the rows of its tile, four rows in flight; workgroups b and b+8 (one XCD) work on one band of rows.
+template <bool NT>
+__global__ __launch_bounds__(256) void mix_tile(const double* __restrict__ x, const double* __restrict__ b, const double* __restrict__ c,
+                                                double* __restrict__ xo, double* __restrict__ cb, i64 ld, i64 cld, int rpb, int ncb, int nrc) {
+  const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, rpx = nrc >> 3;
+  const int rc = xcd * rpx + w / ncb, cbk = w % ncb;
+  const i64 col = ((i64)cbk * 256 + threadIdx.x) * 2;
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  for (i64 j = (i64)rc * rpb; j < (i64)(rc + 1) * rpb; j += 4) {
+    double2 xv[4], bv[4]; double cv[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xv[q] = *(const double2*)(x + (j + q) * ld + col); bv[q] = *(const double2*)(b + (j + q) * ld + col); }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) cv[q] = c[(j / 2 + q) * cld + col / 2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dv2 o = {xv[q].x + bv[q].x + cv[q / 2], xv[q].y + bv[q].y};
+      if (NT) __builtin_nontemporal_store(o, (dv2*)(xo + (j + q) * ld + col)); else *(dv2*)(xo + (j + q) * ld + col) = o;
+      if ((q & 1) == 0) { if (NT) __builtin_nontemporal_store(o.x + o.y, cb + (j / 2 + q / 2) * cld + col / 2); else cb[(j / 2 + q / 2) * cld + col / 2] = o.x + o.y; }
+    }
+  }
+}
+// The same bytes, one workgroup per 2 rows x 512 columns, in row-major order of the workgroups: no loop, nobody ever
+// waits for a store (loads and stores of a wave complete in order on this architecture, so a loop that stores and
+// then loads again waits for its own stores).
+template <bool NT>
+__global__ __launch_bounds__(256) void mix_flat(const double* __restrict__ x, const double* __restrict__ b, const double* __restrict__ c,
+                                                double* __restrict__ xo, double* __restrict__ cb, i64 ld, i64 cld, int ncb) {
+  const i64 j = (i64)(blockIdx.x / ncb) * 2, col = ((i64)(blockIdx.x % ncb) * 256 + threadIdx.x) * 2;
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  const double2 x0 = *(const double2*)(x + j * ld + col), x1 = *(const double2*)(x + (j + 1) * ld + col);
+  const double2 b0 = *(const double2*)(b + j * ld + col), b1 = *(const double2*)(b + (j + 1) * ld + col);
+  const double cv = c[(j / 2) * cld + col / 2];
+  dv2 o0 = {x0.x + b0.x + cv, x0.y + b0.y}, o1 = {x1.x + b1.x + cv, x1.y + b1.y};
+  if (NT) { __builtin_nontemporal_store(o0, (dv2*)(xo + j * ld + col)); __builtin_nontemporal_store(o1, (dv2*)(xo + (j + 1) * ld + col));
+            __builtin_nontemporal_store(o0.x + o1.y, cb + (j / 2) * cld + col / 2); }
+  else { *(dv2*)(xo + j * ld + col) = o0; *(dv2*)(xo + (j + 1) * ld + col) = o1; cb[(j / 2) * cld + col / 2] = o0.x + o1.y; }
+}
+// The tile shape again, but with the loads running AHEAD rows in front of their use in a register ring (as the fused
+// pass does), so that a wave never waits for the stores it has just issued.
+template <bool NT, int AHEAD>
+__global__ __launch_bounds__(256) void mix_tile_ahead(const double* __restrict__ x, const double* __restrict__ b, const double* __restrict__ c,
+                                                      double* __restrict__ xo, double* __restrict__ cb, i64 ld, i64 cld, int rpb, int ncb, int nrc) {
+  const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, rpx = nrc >> 3;
+  const int rc = xcd * rpx + w / ncb, cbk = w % ncb;
+  const i64 col = ((i64)cbk * 256 + threadIdx.x) * 2;
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  const i64 j0 = (i64)rc * rpb;
+  double2 xv[AHEAD], bv[AHEAD]; double cv[AHEAD / 2];
+#pragma unroll
+  for (int q = 0; q < AHEAD; ++q) { xv[q] = *(const double2*)(x + (j0 + q) * ld + col); bv[q] = *(const double2*)(b + (j0 + q) * ld + col); }
+#pragma unroll
+  for (int q = 0; q < AHEAD / 2; ++q) cv[q] = c[(j0 / 2 + q) * cld + col / 2];
+  for (i64 j = j0; j < j0 + rpb; j += AHEAD) {
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) {
+      dv2 o = {xv[q].x + bv[q].x + cv[q / 2], xv[q].y + bv[q].y};
+      const i64 jn = j + q + AHEAD < j0 + rpb ? j + q + AHEAD : j + q; // the tile's last rows are loaded twice
+      xv[q] = *(const double2*)(x + jn * ld + col); bv[q] = *(const double2*)(b + jn * ld + col);
+      if (NT) __builtin_nontemporal_store(o, (dv2*)(xo + (j + q) * ld + col)); else *(dv2*)(xo + (j + q) * ld + col) = o;
+      if ((q & 1) == 1) {
+        if (NT) __builtin_nontemporal_store(o.x + o.y, cb + ((j + q) / 2) * cld + col / 2); else cb[((j + q) / 2) * cld + col / 2] = o.x + o.y;
+        cv[q / 2] = c[(jn / 2) * cld + col / 2];
+      }
+    }
+  }
+}
 int main(int argc, char** argv) {
   i64 ny = 32768, ld = 32768 + 16;
   i64 n = ny * ld, n2 = n / 2;
@@ -114,6 +184,32 @@ int main(int argc, char** argv) {
     char nm[64]; snprintf(nm, 64, "add_tile (2R1W) rpb=%d", rpb);
     int ncb = 32768 / 512;
     report(nm, 3.0 * ny * 32768 * 8, [&] { hipLaunchKernelGGL(add_tile, dim3(ncb * (ny / rpb)), dim3(256), 0, 0, a, b, o, ld, rpb, ncb); });
+  }
+  { // the finest pass's byte mix, on arrays of its sizes (x, b, x' of 32768 x 32784, coarse arrays a quarter of that)
+    double *c, *cbv; i64 cld = 16384 + 16, cn = 16384 * cld;
+    CK(hipMalloc(&c, cn * 8)); CK(hipMalloc(&cbv, cn * 8)); CK(hipMemset(c, 1, cn * 8)); CK(hipMemset(cbv, 0, cn * 8));
+    const double bytes = 28.0 * ny * 32768;
+    for (int rpb : {64, 128, 512}) {
+      char nm[64]; int ncb = 32768 / 512, nrc = (int)(ny / rpb);
+      snprintf(nm, 64, "mix_tile (28 B/pt) rpb=%d", rpb);
+      report(nm, bytes, [&] { hipLaunchKernelGGL(mix_tile<false>, dim3(ncb * nrc), dim3(256), 0, 0, a, b, c, o, cbv, ld, cld, rpb, ncb, nrc); });
+      snprintf(nm, 64, "mix_tile nt stores rpb=%d", rpb);
+      report(nm, bytes, [&] { hipLaunchKernelGGL(mix_tile<true>, dim3(ncb * nrc), dim3(256), 0, 0, a, b, c, o, cbv, ld, cld, rpb, ncb, nrc); });
+    }
+    report("mix_flat (2 rows x 512 cols)", bytes, [&] { hipLaunchKernelGGL(mix_flat<false>, dim3(64 * (unsigned)(ny / 2)), dim3(256), 0, 0, a, b, c, o, cbv, ld, cld, 64); });
+    report("mix_flat nt stores", bytes, [&] { hipLaunchKernelGGL(mix_flat<true>, dim3(64 * (unsigned)(ny / 2)), dim3(256), 0, 0, a, b, c, o, cbv, ld, cld, 64); });
+    for (int rpb : {64, 256}) {
+      char nm[64]; int ncb = 32768 / 512, nrc = (int)(ny / rpb);
+      snprintf(nm, 64, "mix_tile_ahead<4> nt rpb=%d", rpb);
+      report(nm, bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<true, 4>), dim3(ncb * nrc), dim3(256), 0, 0, a, b, c, o, cbv, ld, cld, rpb, ncb, nrc); });
+      snprintf(nm, 64, "mix_tile_ahead<8> nt rpb=%d", rpb);
+      report(nm, bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<true, 8>), dim3(ncb * nrc), dim3(256), 0, 0, a, b, c, o, cbv, ld, cld, rpb, ncb, nrc); });
+      snprintf(nm, 64, "mix_tile_ahead<8> rpb=%d", rpb);
+      report(nm, bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<false, 8>), dim3(ncb * nrc), dim3(256), 0, 0, a, b, c, o, cbv, ld, cld, rpb, ncb, nrc); });
+    }
+    // the same with the roles of the arrays exchanged: which allocation is written decides as much as the kernel
+    report("mix_tile nt rpb=64, writes a", bytes, [&] { hipLaunchKernelGGL(mix_tile<true>, dim3(64 * 512), dim3(256), 0, 0, o, b, c, a, cbv, ld, cld, 64, 64, 512); });
+    report("mix_tile nt rpb=64, writes b", bytes, [&] { hipLaunchKernelGGL(mix_tile<true>, dim3(64 * 512), dim3(256), 0, 0, o, a, c, b, cbv, ld, cld, 64, 64, 512); });
   }
   return 0;
 }
