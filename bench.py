@@ -41,6 +41,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# RCCL and CUDA-tensor sharing between processes need dmabuf IPC handles on hosts whose driver supports no other kind
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 

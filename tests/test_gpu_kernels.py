@@ -682,3 +682,70 @@ def test_gauss_seidel_redblack_vs_oracle(shape):
         got = dx[:, :nx].cpu().numpy()
         assert np.array_equal(got[:10], x[:10]) and np.array_equal(got[20:], x[20:]) and not np.array_equal(got[10:20], x[10:20])
     assert lib.mg_gauss_seidel_rb(db.data_ptr(), dx.data_ptr(), ny, nx, ld, 0, ny, 0.3, 0, 1, 0, st) != 0
+
+
+# the modes of the fused pass that the V-cycle launches, each against the oracle's kernels directly:
+# (name, sweeps, prolong_after, start from zero, prolongation, residual, restriction, x stored)
+FUSED_MODES = [("finest", 6, 0, False, True, True, True, True), ("opening", 1, 0, False, False, True, True, True),
+               ("descent", 3, 0, True, False, True, True, True), ("descent without x", 3, 0, True, False, True, True, False),
+               ("ascent", 6, 0, False, True, False, False, True), ("ascent recomputed", 9, 3, True, True, False, False, True),
+               ("plain", 3, 0, False, False, False, False, True)]
+
+
+@pytest.mark.parametrize("shape", [(33, 33), (129, 257), (257, 1025), (65, 4097)], ids=str)
+@pytest.mark.parametrize("mode", FUSED_MODES, ids=lambda m: m[0])
+def test_fused_pass_equals_oracle_kernels(L, shape, mode):
+    """Every mode of mg_smooth_fused / mg_smooth_fused_restrict that the cycle uses == the same sequence of the
+    oracle's kernels (interpolate_add_to, smooth_sweep_jacobi, residual, coarse: core/numba_modules.py:53-66, :35-50,
+    :132-160, :163-180) on the whole grid, bit for bit: x, r, the max-norm and the coarse right-hand side."""
+    import ctypes as C
+    import torch
+    name, sweeps, after, zero, prolong, resid, restrict, store_x = mode
+    ny, nx = shape
+    cny, cnx = (ny - 1) // 2 + 1, (nx - 1) // 2 + 1
+    rng = np.random.default_rng(ny + 5 * nx + sweeps)
+    h = 0.3
+    b = rng.standard_normal(shape)
+    x = np.zeros(shape) if zero else rng.standard_normal(shape)
+    c = rng.standard_normal((cny, cnx))
+    c[0] = c[-1] = 0
+    c[:, 0] = c[:, -1] = 0
+    # the oracle's sequence
+    want, tmp = x.copy(), x.copy()
+    for k in range(sweeps):
+        if prolong and k == after:
+            oracle.interpolate_add_to(c, want, 0, 0)
+            tmp[:] = want
+        oracle.smooth_sweep_jacobi(b, want, tmp, h)
+    r_want, cb_want = np.zeros(shape), np.zeros((cny, cnx))
+    if resid:
+        oracle.residual(r_want, want, b, h)
+    if restrict:
+        oracle.coarse(r_want, cb_want, 0, 0)
+    # the fused pass
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    db, dx, dc = padded(b), padded(x), padded(c)
+    out, rr, cb = padded(x), padded(np.zeros(shape)), padded(np.zeros((cny, cnx)))
+    ld, cld = db.stride(0), dc.stride(0)
+    slots = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
+    xin = None if zero else dx.data_ptr()
+    xo = out.data_ptr() if store_x else None
+    cargs = (dc.data_ptr() if prolong else None, ny, nx, ld, cny if prolong else 0, cnx if prolong else 0, cld if prolong else 0,
+             1, ny - 1, 0, ny - 1, 0, sweeps)
+    if restrict:
+        assert after == 0
+        L.check(lib.mg_smooth_fused_restrict(db.data_ptr(), xin, xo, rr.data_ptr(), *cargs, h, 1.0, slots.data_ptr(), 0,
+                                             cb.data_ptr(), cny, cnx, cb.stride(0), 1, cny - 1, 1, 0, 0, 0, st))
+    else:
+        L.check(lib.mg_smooth_fused(db.data_ptr(), xin, xo, rr.data_ptr() if resid else None, *cargs, after, h, 1.0,
+                                    slots.data_ptr() if resid else None, 1, 0, 0, st))
+    if store_x:
+        assert np.array_equal(out[:, :nx].cpu().numpy(), want)
+    if resid:
+        assert np.array_equal(rr[:, :nx].cpu().numpy(), r_want)
+        nrm = C.c_double()
+        L.check(lib.mg_norm_read(slots.data_ptr(), C.byref(nrm), st))
+        assert nrm.value == np.abs(r_want[1:-1, 1:-1]).max()
+    if restrict:
+        assert np.array_equal(cb[:, :cnx].cpu().numpy(), cb_want)
