@@ -61,12 +61,11 @@ class SlabMultigrid:
         self.world, self.rank = world, rank
         # fine_smoother: "jacobi" = the reference's sweep on the Jacobi levels; "redblack" = red-black Gauss-Seidel
         # sweeps in their place (same counts n1/n2; damps the checkerboard mode that undamped Jacobi leaves alone).
-        # One kernel per colour and operation, one rank: the fused passes are Jacobi pipelines.
+        # One kernel per colour and operation (the fused passes are Jacobi pipelines); on several ranks one halo row is
+        # exchanged after every colour.
         if fine_smoother not in ("jacobi", "redblack"):
             raise ValueError("fine_smoother must be 'jacobi' or 'redblack'")
         if fine_smoother == "redblack":
-            if world != 1:
-                raise ValueError("fine_smoother='redblack' runs on one rank")
             fused = False
         self.fine_smoother = fine_smoother
         self.fused = fused and getattr(ops, "supports_fused", False)
@@ -587,24 +586,12 @@ class SlabMultigrid:
             if restrict:
                 after_restriction()
             return src
-        if self.fine_smoother == "redblack":  # in place: no second array
-            if src is None:
-                src = xa
-                o.zero_(src)
-            elif crs is not None:
-                o.prolong_add(crs, cnx, src, L.nx, L.t0, L.t1, 0, L.oj)
-            for _ in range(n):
-                o.gauss_seidel_rb(self.b[l], src, L.nx, L.t0, L.t1, L.h, row_offset=L.halo)
-            if r is not None:
-                if norm is not None:
-                    o.norm_reset(norm)
-                o.residual(r, src, self.b[l], L.nx, L.t0, L.t1, L.h, norm, finest)
-            if restrict:
-                assert r is self.r[l]
-                o.restrict(self.r[l], L.nx, cb, Lc.nx, Lc.t0, Lc.t1, 0, L.oj)
-            return src
-        # one kernel per operation, one single-row exchange per sweep
-        if src is None:
+        # one kernel per operation, one single-row exchange per sweep (red-black: per colour, and in place)
+        redblack = self.fine_smoother == "redblack"
+        if src is None and redblack:
+            src = xa
+            o.zero_(src)
+        elif src is None:
             o.jacobi_from_zero(self.b[l], xa, L.nx, L.t0, L.t1, L.h, finest, omega=self.jacobi_omega)
             src, n = xa, n - 1
         else:
@@ -613,6 +600,12 @@ class SlabMultigrid:
         if dist_:
             self._exchange([(src, L, 1)])
         for _ in range(n):
+            if redblack:
+                for colour in (0, 1):  # the second colour reads the first one's values across the slab boundary
+                    o.gauss_seidel_rb(self.b[l], src, L.nx, L.t0, L.t1, L.h, row_offset=L.halo, colour=colour)
+                    if dist_:
+                        self._exchange([(src, L, 1)])
+                continue
             dst = xb if src is xa else xa
             o.jacobi(self.b[l], src, dst, L.nx, L.t0, L.t1, L.h, finest, omega=self.jacobi_omega)
             if dist_:
@@ -651,6 +644,10 @@ class SlabMultigrid:
             return 0
         k = self.n_dist
         if not self.fused:
+            # per sweep one exchange (red-black: two), one after the start (zero or the prolongation), one of r before
+            # the restriction; 1 + 6 + 1 on the finest level, (1 + 3 + 1) + (1 + 6) on the others; the all-gather
+            if self.fine_smoother == "redblack":
+                return 14 + 21 * (k - 1) + 1
             return 8 + 11 * (k - 1) + 1
         total = 2  # finest level: (x, correction) before its pass, b_1 (or the all-gather) after it
         for l in range(1, k):

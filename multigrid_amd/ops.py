@@ -194,12 +194,13 @@ class HipOps:
             check(self.L.mg_smooth_fused_restrict(*common, h, omega, p(norm), nstride, p(coarse_b), cbny, cbnx, cbld, T0, T1, nb,
                                                   bs, cs, cbs, self._s))
 
-    def gauss_seidel_rb(self, b, x, nx, j0, j1, h, row_offset=0):
+    def gauss_seidel_rb(self, b, x, nx, j0, j1, h, row_offset=0, colour=None):
         """One red-black Gauss-Seidel sweep in place: first the cells with even (global row + column), then the odd
-        ones.  row_offset: local row of global row 0 (the halo depth), so that the colours are those of the grid."""
+        ones; colour = 0 / 1: only that half of it.  row_offset: local row of global row 0 (the halo depth), so that
+        the colours are those of the grid."""
         self._same_layout(b, x)
         nb, bs, ny, ld = self._nb(x)
-        for colour in (0, 1):
+        for colour in ((0, 1) if colour is None else (colour,)):
             check(self.L.mg_gauss_seidel_rb(b.data_ptr(), x.data_ptr(), ny, nx, ld, j0, j1, h, (colour + row_offset) & 1, nb, bs,
                                             self._s))
 

@@ -28,7 +28,9 @@ def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, fused, dist_min_r
         a, e = eng.owned_rows()
         eng.set_b_rows(torch.from_numpy(b[rank * R : rank * R + (e - a)]).cuda())
         eng.presmooth()
+        before = eng.comm.rounds
         errs = eng.cycles(cycles)
+        assert eng.comm.rounds - before == cycles * eng.rounds_per_cycle(), (eng.comm.rounds - before, eng.rounds_per_cycle())
         if kw and kw.get("overlap_min_rows") == 1:  # the finest pass of every cycle at least was cut
             assert eng.split_passes >= cycles + 1 and eng._pending is None
         x = eng.local_rows(eng.x0).cpu().numpy()
@@ -56,13 +58,21 @@ def test_ranks_with_split_passes_equal_oracle(world, gny, gnx, n_para, dist_min_
     _run(world, gny, gnx, n_para, True, dist_min_rows, dict(overlap_min_rows=1, recompute_presmoothing=recompute))
 
 
-def _run(world, gny, gnx, n_para, fused, dist_min_rows, kw=None):
+# red-black Gauss-Seidel on the fine levels (an option outside the reference): one launch per colour, one halo row
+# exchanged after every colour
+@pytest.mark.parametrize("world,gny,gnx,n_para,dist_min_rows", [(2, 257, 257, 3, 8), (4, 1025, 513, 5, 64), (3, 769, 1201, 2, 8)],
+                         ids=str)
+def test_ranks_with_redblack_fine_smoother_equal_oracle(world, gny, gnx, n_para, dist_min_rows):
+    _run(world, gny, gnx, n_para, False, dist_min_rows, dict(fine_smoother="redblack"), dict(fine_smoother="redblack"))
+
+
+def _run(world, gny, gnx, n_para, fused, dist_min_rows, kw=None, ref_kw=None):
     rng = np.random.default_rng(1)
     b = rng.standard_normal((gny, gnx))
     b[0] = b[-1] = 0
     b[:, 0] = b[:, -1] = 0
     h, cycles = 0.37, 3
-    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0)
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0, **(ref_kw or {}))
     ref.b[:] = b
     ref.solve(ncycles=cycles)
     from tests.mp_util import run_ranks
