@@ -498,3 +498,35 @@ def test_nonzero_dirichlet_boundary(fused):
     rel = np.linalg.norm(x - x_direct) / np.linalg.norm(x_direct)
     assert rel < 1e-10, (total, err, rel)
     eng.close()
+
+
+# several knobs at once, each away from its default: (key, value, default)
+KNOB_SETS = [[("stream_min_mib", 0, 256), ("fused_lockstep", 3, 1), ("fused_rows", 24, 0)],
+             [("stream_min_mib", 0, 256), ("fused_waves", 2, 4), ("fused_rows_shallow", 8, 32), ("fused_rows_deep", 16, 128)],
+             [("fused_lockstep", 0, 1), ("xcd_stagger", -1, 0), ("fused_min_rows", 4, 8), ("fused_min_blocks", 1 << 20, 2048)]]
+
+
+@pytest.mark.parametrize("knobs", KNOB_SETS, ids=lambda ks: "+".join(f"{k}={v}" for k, v, _ in ks))
+@pytest.mark.parametrize("fused", [True, False])
+def test_cycle_equals_oracle_under_tuning_knobs(knobs, fused):
+    """Whole V-cycles with the tuning knobs away from their defaults (streaming stores on every array, other tile
+    heights, strips per workgroup and barrier spacings): still the oracle's numbers, bit for bit."""
+    from multigrid_amd import _lib as L
+    gny, gnx, n_para, h = 513, 2049, 5, 0.37
+    b = _rhs(gny, gnx, 11)
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0)
+    ref.b[:] = b
+    ref.solve(ncycles=3)
+    lib = L.lib()
+    for key, value, _ in knobs:
+        L.check(lib.mg_set_tuning(key.encode(), value))
+    try:
+        eng = _make(gny, gnx, n_para, h, 0.0, b, fused=fused, recompute_min_nx=0, recompute_min_blocks=0, eager_dead_levels=True)
+        eng.presmooth()
+        errs = eng.cycles(3)
+        assert errs == ref.err_hist.tolist()
+        assert np.array_equal(_rows(eng, eng.x0), ref.x) and np.array_equal(_rows(eng, eng.r0), ref.r)
+        eng.close()
+    finally:
+        for key, _, default in knobs:
+            L.check(lib.mg_set_tuning(key.encode(), default))

@@ -698,6 +698,33 @@ def test_fused_pass_equals_oracle_kernels(L, shape, mode):
     """Every mode of mg_smooth_fused / mg_smooth_fused_restrict that the cycle uses == the same sequence of the
     oracle's kernels (interpolate_add_to, smooth_sweep_jacobi, residual, coarse: core/numba_modules.py:53-66, :35-50,
     :132-160, :163-180) on the whole grid, bit for bit: x, r, the max-norm and the coarse right-hand side."""
+    _fused_vs_oracle(L, shape, mode)
+
+
+# tuning knobs change how a pass is cut into tiles, how its waves synchronise and which kind of store it uses,
+# never a value: (key, value, key's default)
+KNOBS = [("stream_min_mib", 0, 256), ("fused_lockstep", 0, 1), ("fused_lockstep", 3, 1), ("fused_rows", 7, 0), ("fused_rows", 24, 0),
+         ("fused_rows", 256, 0), ("fused_rows_shallow", 64, 32), ("fused_rows_deep", 32, 128), ("fused_waves", 1, 4),
+         ("fused_waves", 2, 4), ("xcd_stagger", -1, 0), ("xcd_stagger", 3, 0), ("fused_min_rows", 4, 8), ("fused_min_blocks", 1, 2048)]
+
+
+@pytest.mark.parametrize("knob", KNOBS, ids=lambda k: f"{k[0]}={k[1]}")
+@pytest.mark.parametrize("mode", FUSED_MODES, ids=lambda m: m[0])
+def test_fused_pass_equals_oracle_under_every_tuning_knob(L, knob, mode):
+    """The same comparison with each tuning knob away from its default (streaming stores forced onto small arrays, no
+    or rarer lockstep barriers, short and tall tiles, fewer strips per workgroup, shifted XCD bands), on shapes with
+    partly filled workgroups (641 and 1409 columns: 6 and 13 strips) and with ragged last tiles."""
+    key, value, default = knob
+    lib = L.lib()
+    L.check(lib.mg_set_tuning(key.encode(), value))
+    try:
+        for shape in [(65, 641), (161, 1409), (1025, 129)]:
+            _fused_vs_oracle(L, shape, mode)
+    finally:
+        L.check(lib.mg_set_tuning(key.encode(), default))
+
+
+def _fused_vs_oracle(L, shape, mode):
     import ctypes as C
     import torch
     name, sweeps, after, zero, prolong, resid, restrict, store_x = mode
