@@ -314,7 +314,7 @@ def main():
         ms = 1e3 * dt / args.steps
         # HBM bytes per launch of the dominant kernel from rocprofv3 counters: measured on tools/pmc_probe.py at
         # 32769 x 32769 and kept in profiles/traffic.json with a digest of the kernel sources it was measured on
-        traffic, traffic_source = None, None
+        traffic, traffic_source, cycle_traffic = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if n != 14 or args.batch or world != 1:
             traffic_source = "not measured for this workload (profiles/traffic.json holds the 32769 x 32769 launches)"
@@ -326,6 +326,8 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("csrc_sha256") == sources_digest():
                     traffic = tj.get(tkey)
+                    if eng.fused and eng.eager_dead_levels and not args.no_recompute and args.jacobi_omega == 1.0 and args.ordering == "lexicographic":
+                        cycle_traffic = (tj.get("cycle") or {}).get("hbm_bytes")
                     traffic_source = ("static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/pmc_probe.py, "
                                       "same kernel sources, sha256 " + tj["csrc_sha256"][:12] + "); not collected in this run")
                 else:
@@ -373,6 +375,8 @@ def main():
             "cycle": {
                 "own_bytes": own_cyc, "gbps_per_gpu": own_cyc / world / (ms * 1e-3) / 1e9,
                 "frac_of_peak": own_cyc / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                # counters summed over every kernel of one cycle (same source and conditions as roofline.traffic)
+                "traffic": cycle_traffic, "traffic_over_own_bytes": (cycle_traffic / own_cyc) if cycle_traffic else None,
                 "algorithmic_equivalent_bytes": bcyc, "algorithmic_equivalent_gbps_per_gpu": bcyc / world / (ms * 1e-3) / 1e9,
                 "max_abs_r_after_last_cycle": errs[-1] if errs else None,
             },

@@ -5,7 +5,13 @@
 
 Counter collection serialises dispatches and is slow, so this probe launches each kernel of the
 V-cycle's finest level a few times on a 32769 x 32769 grid and nothing else (no graph, no
-right-hand-side generation: the arrays are filled by one torch call each)."""
+right-hand-side generation: the arrays are filled by one torch call each).
+
+    ... -- python3 tools/pmc_probe.py --cycle
+
+launches whole V-cycles instead: the engine of bench.py's default workload (n_para = n - 4, dead whole-domain levels
+computed every cycle) without graph and without placement selection, the opening pass and three cycles, kernel by
+kernel; tools/pmc_summary.py adds up the middle cycle (the last one also stores the residual array)."""
 import argparse
 import os
 import sys
@@ -19,8 +25,24 @@ def main():
     ap.add_argument("--n", type=int, default=14)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--fused-rows", type=int, default=0, help="tile height of the fused passes (0 = automatic)")
+    ap.add_argument("--cycle", action="store_true", help="whole V-cycles of the engine instead of single kernels")
     args = ap.parse_args()
     import torch
+    if args.cycle:
+        from multigrid_amd.engine import SlabMultigrid
+        N = 2 ** (args.n + 1) + 1
+        eng = SlabMultigrid(N, N, max(1, args.n - 4), 20.0 / 2 ** (args.n + 1), 0.0, world=1, rank=0, eager_dead_levels=True,
+                            use_graph=False, tune_placement=False)
+        b = torch.rand((N, N), dtype=torch.float64, device="cuda")
+        b[0] = b[-1] = 0
+        b[:, 0] = b[:, -1] = 0
+        eng.set_b_rows(b)
+        del b
+        eng.presmooth()
+        errs = eng.cycles(3)
+        torch.cuda.synchronize()
+        print(f"grid {N}x{N}, n_para {eng.n_para}: 3 cycles, max|r| {errs}", flush=True)
+        return
     from multigrid_amd.levels import make_plan
     from multigrid_amd.ops import HipOps
 

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Turn the two rocprofv3 --pmc passes over tools/pmc_probe.py into HBM bytes per launch.
 
-    python tools/pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv [--n 14] > profiles/traffic.json
+    python tools/pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv [--n 14]
+                                [--cycle-fetch csv --cycle-write csv] > profiles/traffic.json
+
+The optional second pair are the same two passes over `tools/pmc_probe.py --cycle`: the counters of every kernel of
+one whole V-cycle (the second of three: from after the first launch of the cycle's finest pass to the second) added up.
 
 FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts half of the bytes of
 16-byte-per-lane streaming reads, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.
@@ -26,6 +30,23 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+FINEST = "mg_fused_kernel<6, true, false, true, true"
+
+
+def one_cycle(path, counter):
+    """Sum of the counter over the dispatches of the second V-cycle, and their number."""
+    rows = []
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == counter and "mg_" in row["Kernel_Name"]:
+                rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"])))
+    rows.sort()
+    ends = [i for i, r in enumerate(rows) if FINEST in r[1]]
+    assert len(ends) >= 2, "the trace holds fewer than two cycles"
+    part = rows[ends[0] + 1 : ends[1] + 1]
+    return sum(r[2] for r in part), len(part)
+
+
 # bytes per updated finest-level point: (per-operation compulsory bytes x the operations of the launch,
 # what the launch itself must move)
 BYTES = {
@@ -48,6 +69,8 @@ def main():
     ap.add_argument("fetch_csv")
     ap.add_argument("write_csv")
     ap.add_argument("--n", type=int, default=14)
+    ap.add_argument("--cycle-fetch")
+    ap.add_argument("--cycle-write")
     args = ap.parse_args()
     pts = (2 ** (args.n + 1) - 1) ** 2
     fetch = per_kernel(args.fetch_csv, "FETCH_SIZE")
@@ -76,6 +99,14 @@ def main():
                 "streaming reads, WRITE_SIZE (KiB) as is; averages over the launches of each kernel",
         "kernels": kernels,
     }
+    if args.cycle_fetch and args.cycle_write:
+        f, nk = one_cycle(args.cycle_fetch, "FETCH_SIZE")
+        w, nk2 = one_cycle(args.cycle_write, "WRITE_SIZE")
+        assert nk == nk2, (nk, nk2)
+        out["cycle"] = {"fetch_bytes": 2 * 1024 * f, "write_bytes": 1024 * w, "hbm_bytes": 2 * 1024 * f + 1024 * w, "kernels": nk,
+                        "note": "every kernel of one V-cycle of bench.py's default workload (tools/pmc_probe.py --cycle, launched "
+                                "kernel by kernel, no placement selection), same corrections; the small kernels' access widths are "
+                                "not calibrated, they carry under 2 % of the bytes"}
     json.dump(out, sys.stdout, indent=1)
     print()
 
