@@ -281,6 +281,15 @@ def main():
     single = {"kernel": "mg_stencil5_kernel<0 (Jacobi), 2, 1, streaming stores when the array is >= 256 MiB>", "avg_launch_ms": sweep_ms,
               "bytes_per_launch": 24 * pts_launch, "achieved": 24 * pts_launch / (sweep_ms * 1e-3) / 1e9}
     single["frac"] = single["achieved"] / HBM_PEAK_GBPS
+
+    # what a plain device-to-device copy of one finest-level array reaches on this device, right now
+    def plain_copy(k):
+        with ops.ctx():
+            xs[1 - (k & 1)].copy_(xs[k & 1])
+    copy_ms = timed(plain_copy)
+    copy_bytes = 2 * xs[0].numel() * 8
+    device_copy = {"what": "tensor.copy_ of one finest-level x array (read + write)", "bytes": copy_bytes, "avg_ms": copy_ms,
+                   "gbps": copy_bytes / (copy_ms * 1e-3) / 1e9}
     if eng.fused:
         # the correction and the restriction target as the cycle passes them: slab arrays of level 1, or, when
         # level 1 is replicated on every rank, this rank's window of it and the slab that is all-gathered
@@ -371,6 +380,8 @@ def main():
                             "restriction 10 B per point): a throughput equivalent for comparison with unfused code, not a bandwidth",
                 },
                 "single_jacobi_sweep": single,
+                # the same achieved rate against a measured ceiling of the device instead of the specification's
+                "device_copy": device_copy, "achieved_over_device_copy": achieved / device_copy["gbps"],
             },
             "cycle": {
                 "own_bytes": own_cyc, "gbps_per_gpu": own_cyc / world / (ms * 1e-3) / 1e9,
