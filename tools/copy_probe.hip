@@ -211,5 +211,27 @@ int main(int argc, char** argv) {
     report("mix_tile nt rpb=64, writes a", bytes, [&] { hipLaunchKernelGGL(mix_tile<true>, dim3(64 * 512), dim3(256), 0, 0, o, b, c, a, cbv, ld, cld, 64, 64, 512); });
     report("mix_tile nt rpb=64, writes b", bytes, [&] { hipLaunchKernelGGL(mix_tile<true>, dim3(64 * 512), dim3(256), 0, 0, o, a, c, b, cbv, ld, cld, 64, 64, 512); });
   }
+  { // Does a read that follows a write of the same data closely find it in the Infinity Cache?  One array is written
+    // and read back band by band (a write launch, then a read launch of the same band), for several band sizes;
+    // against writing all of it and then reading all of it.
+    const i64 total2 = n2; // double2 elements
+    auto pass = [&](i64 band2, bool nt) {
+      for (i64 off = 0; off < total2; off += band2) {
+        const i64 m = off + band2 <= total2 ? band2 : total2 - off;
+        const unsigned blocks = (unsigned)((m + 255) / 256 < 65536 ? (m + 255) / 256 : 65536);
+        if (nt) hipLaunchKernelGGL(copy_gs<true>, dim3(blocks), dim3(256), 0, 0, (const double2*)b + off, (double2*)o + off, m);
+        else hipLaunchKernelGGL(copy_gs<false>, dim3(blocks), dim3(256), 0, 0, (const double2*)b + off, (double2*)o + off, m);
+        hipLaunchKernelGGL(read_gs, dim3(blocks), dim3(256), 0, 0, (const double2*)o + off, a, m);
+      }
+    };
+    for (int mb : {8192, 1024, 256, 128, 64, 32, 16}) {
+      char nm[64];
+      const i64 band2 = (i64)mb * (1 << 20) / 16;
+      snprintf(nm, 64, "copy+readback band %d MiB", mb);
+      report(nm, 3.0 * n * 8, [&] { pass(band2, false); });
+      snprintf(nm, 64, "same, nt copy, band %d MiB", mb);
+      report(nm, 3.0 * n * 8, [&] { pass(band2, true); });
+    }
+  }
   return 0;
 }
