@@ -218,8 +218,8 @@ class SlabMultigrid:
         slow again and one allocated before them fast.  It is fixed when the allocations are made and survives
         the release of others; distances between the arrays inside one allocation, tile shapes and the XCD
         mapping do not matter; pure reads and pure writes of every array run at the same rate; the address-
-        translation and L2 counters of a slow and a fast launch agree (tools/placement_*.py,
-        profiles/r02_placement.md).  The cause below the allocation interface was not found, so set-up measures:
+        translation and L2 counters of a slow and a fast launch agree (tools/placement_*.py, whose outputs are kept
+        under profiles/).  The cause below the allocation interface was not found, so set-up measures:
         the coarse right-hand side is allocated first AND KEPT (it becomes the engine's own), candidates of the
         finest array's size are allocated one by one, each is timed as the output of the pass, and as soon as
         both kinds have been seen and four candidates are of the fast kind those become x (two arrays), b and r
