@@ -82,8 +82,44 @@ static double *vmm_array(size_t bytes, size_t chunk, int order /*0 in order, 1 r
     return (double *)va;
 }
 
-int main()
+// `vmm_probe first`: the hand-mapped candidates come FIRST (small chunks, scrambled; then in order), the plain
+// allocations after them: separates the chunking from the position in the process's sequence of allocations.
+static int chunks_first()
 {
+    const size_t bytes = (size_t)N * LD * 8, cbytes = (size_t)CN * CLD * 8, MiB = (size_t)1 << 20;
+    CK(hipStreamCreate(&st));
+    CK(hipMalloc((void **)&b, bytes));
+    CK(hipMalloc((void **)&xin, bytes));
+    CK(hipMalloc((void **)&crs, cbytes));
+    CK(hipMalloc((void **)&crs_b, cbytes));
+    CK(hipMalloc((void **)&nrm_slots, 64 * 8));
+    CK(hipMemsetAsync(b, 0, bytes, st));
+    CK(hipMemsetAsync(xin, 0, bytes, st));
+    CK(hipMemsetAsync(crs, 0, cbytes, st));
+    CK(hipMemsetAsync(crs_b, 0, cbytes, st));
+    CK(hipMemsetAsync(nrm_slots, 0, 64 * 8, st));
+    const struct { size_t chunk; int order; } seq[] = {{2 * MiB, 2}, {2 * MiB, 0}, {64 * MiB, 2}, {0, 0}, {0, 0}, {2 * MiB, 2}, {0, 0}, {0, 0},
+                                                       {0, 0}, {0, 0}, {0, 0}, {0, 0}, {2 * MiB, 2}, {0, 0}};
+    for (auto q : seq) {
+        if (q.chunk) {
+            std::vector<hipMemGenericAllocationHandle_t> hs;
+            double *p = vmm_array(bytes, q.chunk, q.order, hs);
+            printf("hipMemCreate chunks of %6zu MiB, %s as x_out: %.3f ms\n", q.chunk / MiB,
+                   q.order == 0 ? "mapped in order" : "mapped scrambled", time_out(p));
+        } else {
+            double *p;
+            CK(hipMalloc((void **)&p, bytes));
+            CK(hipMemsetAsync(p, 0, bytes, st));
+            printf("hipMalloc as x_out: %.3f ms\n", time_out(p));
+        }
+        fflush(stdout);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && argv[1][0] == 'f') return chunks_first();
     const size_t bytes = (size_t)N * LD * 8, cbytes = (size_t)CN * CLD * 8;
     CK(hipStreamCreate(&st));
     double *plain[3];
