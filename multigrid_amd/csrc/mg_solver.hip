@@ -11,6 +11,7 @@
 // grid, bit for bit.
 #include <string.h>
 
+#include <chrono>
 #include <new>
 #include <utility>
 #include <vector>
@@ -296,12 +297,21 @@ int collect_err(mg_solver *s, int a, double *err)
 // With MG_SOLVER_TUNE_PLACEMENT create measures: the coarse right-hand side is allocated first AND KEPT (*cb_out:
 // it becomes the next level's b), candidates of the finest array's size are allocated one by one, each is timed
 // as the output of the cycle's finest pass, and as soon as both kinds have been seen and four candidates are of
-// the fast kind those become fin[] = {xa, xb, b, r}, in the assignment whose pass is fastest; all zero.  fin[]
-// and *cb_out stay null when the level is small (< 1 GiB per array), memory is short or anything fails: create
-// then allocates as usual.
+// the fast kind those become fin[] = {xa, xb, b, r}, in the assignment whose pass is fastest; all zero.
+// On top of that the three big arrays of the pass are spread over the sequence of allocations: measured with thirty
+// candidates, the pass is fastest (by another 2-4 %) when the array it writes shares its stretch of ~96 GiB of
+// that sequence with neither of the two it reads.  So b becomes a candidate of the kind that is slow as an output
+// (it reads as fast as any), one x the fastest output, the other x whichever of a few candidates allocated further
+// along makes the fastest pair in both directions; kept only where that beats the choice among the fast four.
+// No new candidate is allocated once 1.5 s have passed (an 8-GiB allocation takes 5 to 200 ms).  fin[] and *cb_out
+// stay null when the level is small (< 1 GiB per array), memory is short or anything fails: create then allocates
+// as usual.
 void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_out)
 {
-    const int KMAX = 24;
+    const int KMAX = 26, SPREAD = 14;
+    const double BUDGET = 1.5;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
     const i64 ny = s->gny, nx = s->gnx, ld = pitch(nx), n = ny * ld;
     const size_t bytes = (size_t)n * sizeof(double);
     for (int k = 0; k < 4; ++k) fin[k] = nullptr;
@@ -323,10 +333,10 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
               hipMemsetAsync(crs, 0, cbytes, s->stream) == hipSuccess && hipMemsetAsync(cb, 0, cbytes, s->stream) == hipSuccess &&
               hipMemsetAsync(norm, 0, MG_NORM_SLOTS * sizeof(u64), s->stream) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-    auto time_pass = [&](double *b, double *xin, double *xout, float *ms) { // the launch of finest_pass; the first one is not timed
+    auto time_pass = [&](double *b, double *xin, double *xout, float *ms, const double *corr = nullptr) { // the launch of finest_pass; the first one is not timed
         bool good = true;
         for (int rep = 0; rep < 3 && good; ++rep) {
-            good = !mg_smooth_fused_restrict(b, xin, xout, nullptr, crs, ny, nx, ld, cny, cnx, cld, 1, ny - 1, 0, ny - 1, 0, N2,
+            good = !mg_smooth_fused_restrict(b, xin, xout, nullptr, corr ? corr : crs, ny, nx, ld, cny, cnx, cld, 1, ny - 1, 0, ny - 1, 0, N2,
                                              s->h0, 1.0, (uint64_t *)norm, 0, cb, cny, cnx, cld, 1, cny - 1, 1, 0, 0, 0, s->stream);
             if (rep == 0) good = good && hipEventRecord(e0, s->stream) == hipSuccess;
         }
@@ -338,6 +348,7 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
     float ms[KMAX];
     int na = 0, nt = 0; // candidates allocated / timed
     float lo = 0;
+    bool gap = false;
     while (ok && na < kmax) {
         if (hipMalloc((void **)&a[na], bytes) != hipSuccess) { // someone else took the memory: choose among what there is
             (void)hipGetLastError();
@@ -352,7 +363,9 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
         for (int k = 1; k < nt; ++k) lo = ms[k] < lo ? ms[k] : lo, hi = ms[k] > hi ? ms[k] : hi;
         int fast = 0;
         for (int k = 0; k < nt; ++k) fast += ms[k] <= 1.03f * lo;
-        if (hi > 1.06f * lo && fast >= 4) break; // both kinds have been seen (they are 10 % or more apart)
+        gap = hi > 1.06f * lo; // both kinds have been seen (they are 10 % or more apart)
+        if (gap && fast >= 4) break;
+        if (nt >= 4 && elapsed() > BUDGET) break;
     }
     if (ok && nt >= 4) {
         int order[KMAX];
@@ -372,15 +385,55 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
             if (t0 + t1 <= 2 * 1.02f * lo) break;
         }
         const int q3 = 6 - combos[best][0] - combos[best][1] - combos[best][2];
-        const int pick[4] = {order[combos[best][0]], order[combos[best][1]], order[combos[best][2]], order[q3]};
-        for (int q = 0; q < 4 && ok; ++q) { // xa, xb, b, r; the timed launches left values in them: back to zero
+        int pick[4] = {order[combos[best][0]], order[combos[best][1]], order[combos[best][2]], order[q3]};
+        // spread over the sequence of allocations (see above)
+        int slow[2] = {-1, -1};
+        for (int k = 0; k < nt; ++k)
+            if (ms[k] > 1.06f * lo && slow[1] < 0) slow[slow[0] < 0 ? 0 : 1] = k;
+        if (ok && gap && slow[0] >= 0 && na < kmax) {
+            const int n_timed = na;
+            while (ok && na < kmax && na < n_timed + SPREAD && elapsed() < BUDGET) {
+                if (hipMalloc((void **)&a[na], bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                ok = hipMemsetAsync(a[na++], 0, bytes, s->stream) == hipSuccess;
+            }
+            const int xo = pick[0], bk = slow[0], nl = na - n_timed;
+            int tryx[8], ntry = 0;
+            tryx[ntry++] = pick[1];
+            for (int k = n_timed + nl / 2; k < na && ntry < 7; k += 3) tryx[ntry++] = k;
+            if (nl > 0) tryx[ntry++] = na - 1;
+            int xbest = -1;
+            float tspread = 0;
+            for (int q = 0; q < ntry && ok; ++q) {
+                const int xi = tryx[q];
+                bool seen = xi == xo || xi == bk;
+                for (int p = 0; p < q; ++p) seen = seen || tryx[p] == xi;
+                if (seen) continue;
+                float t0 = 0, t1 = 0;
+                ok = time_pass(a[bk], a[xi], a[xo], &t0) && time_pass(a[bk], a[xo], a[xi], &t1);
+                if (ok && (xbest < 0 || t0 + t1 < tspread)) xbest = xi, tspread = t0 + t1;
+            }
+            if (ok && xbest >= 0 && tspread < 0.995f * tbest) {
+                int rk = slow[1];
+                for (int k = 0; k < na && (rk < 0 || rk == xo || rk == xbest || rk == bk); ++k) rk = k;
+                pick[0] = xo, pick[1] = xbest, pick[2] = bk, pick[3] = rk;
+            }
+        }
+        for (int q = 0; q < 4 && ok; ++q) { // xa, xb, b, r
             fin[q] = a[pick[q]];
             a[pick[q]] = nullptr;
-            ok = hipMemsetAsync(fin[q], 0, bytes, s->stream) == hipSuccess;
         }
-        ok = ok && hipMemsetAsync(cb, 0, cbytes, s->stream) == hipSuccess;
         if (ok) s->placement_candidates = nt, *cb_out = cb, cb = nullptr;
     }
+    // the candidates not chosen go back before the next level's are made
+    (void)hipStreamSynchronize(s->stream);
+    for (int k = 0; k < na; ++k)
+        if (a[k]) {
+            (void)hipFree(a[k]);
+            a[k] = nullptr;
+        }
     // The same for the one other pass that writes gigabytes: level 1's ascent pass (1.04 or 1.10 ms at 32769 x 32769
     // depending on the allocation it writes its x into), where that is the 9-stage pass with recomputed
     // pre-smoothing.  Up to eight candidates are timed as its output beside the level's right-hand side (the array
@@ -389,7 +442,7 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
         const i64 strips = (cnx + 107) / 108, blocks = ((strips + 3) / 4) * ((cny - 1 + 63) / 64);
         const i64 c2ny = ((ny - 1) >> 2) + 1, c2nx = ((nx - 1) >> 2) + 1, c2ld = pitch(c2nx);
         double *crs2 = nullptr, *cand[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        float t1[8], lo1 = 0, hi1 = 0;
+        float t1[8], tf[8], lo1 = 0, hi1 = 0; // ms of the level's pass into the candidate; of the finest pass reading it
         int n1 = 0;
         bool ok1 = cnx >= s->recompute_min_nx && blocks >= s->recompute_min_blocks &&
                    hipMalloc((void **)&crs2, (size_t)(c2ny * c2ld) * sizeof(double)) == hipSuccess &&
@@ -407,18 +460,22 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
             }
             ok1 = ok1 && hipEventRecord(e1, s->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                   hipEventElapsedTime(&t1[n1], e0, e1) == hipSuccess;
+            float f0 = 0, f1 = 0; // the candidate is also the correction the finest pass reads
+            ok1 = ok1 && time_pass(fin[2], fin[0], fin[1], &f0, cand[n1]) && time_pass(fin[2], fin[1], fin[0], &f1, cand[n1]);
             if (!ok1) break;
+            tf[n1] = 0.5f * (f0 + f1); // like t1: the time of two launches
             ++n1;
             lo1 = hi1 = t1[0];
             int fast1 = 0;
             for (int k = 1; k < n1; ++k) lo1 = t1[k] < lo1 ? t1[k] : lo1, hi1 = t1[k] > hi1 ? t1[k] : hi1;
             for (int k = 0; k < n1; ++k) fast1 += t1[k] <= 1.01f * lo1;
-            if (n1 >= 3 && hi1 > 1.03f * lo1 && fast1 >= 2) break; // both kinds seen, and the fast one twice
+            if (n1 >= 6 && hi1 > 1.05f * lo1 && fast1 >= 2) break; // both kinds seen (6-8 % apart), and the fast one twice
+            if (elapsed() > BUDGET + 0.5) break;
         }
         if (ok1 && n1 > 0) {
             int best = 0;
             for (int k = 1; k < n1; ++k)
-                if (t1[k] < t1[best]) best = k;
+                if (t1[k] + tf[k] < t1[best] + tf[best]) best = k;
             if (hipMemsetAsync(cand[best], 0, cbytes, s->stream) == hipSuccess) *xa1_out = cand[best], cand[best] = nullptr;
         }
         if (!ok1) (void)hipGetLastError();
@@ -427,6 +484,9 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
             if (q) (void)hipFree(q);
         if (crs2) (void)hipFree(crs2);
     }
+    // the timed launches left values in the chosen arrays: back to zero
+    for (int q = 0; q < 4 && ok && fin[q]; ++q) ok = hipMemsetAsync(fin[q], 0, bytes, s->stream) == hipSuccess;
+    if (ok && *cb_out) ok = hipMemsetAsync(*cb_out, 0, cbytes, s->stream) == hipSuccess;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (!ok) {
         (void)hipGetLastError();
@@ -434,6 +494,10 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
             if (fin[q]) (void)hipFree(fin[q]);
             fin[q] = nullptr;
         }
+        if (*cb_out) (void)hipFree(*cb_out);
+        if (*xa1_out) (void)hipFree(*xa1_out);
+        *cb_out = *xa1_out = nullptr;
+        s->placement_candidates = -1;
     }
     for (int k = 0; k < na; ++k)
         if (a[k]) (void)hipFree(a[k]);

@@ -204,7 +204,9 @@ class SlabMultigrid:
         if tune_placement:
             self.placement_seconds = time.perf_counter() - t0
 
-    PLACE_MAX_CANDIDATES = 24
+    PLACE_MAX_CANDIDATES = 26
+    PLACE_SPREAD_CANDIDATES = 14  # further candidates allocated (not timed one by one) to reach another stretch of the sequence
+    PLACE_BUDGET_SECONDS = 1.5    # no new candidate is allocated after this long (allocating 8 GiB takes 5 to 200 ms)
 
     def _place_finest(self, verbose=False):
         """Choose the finest level's arrays among freshly allocated candidates by how fast the cycle's finest
@@ -239,7 +241,9 @@ class SlabMultigrid:
         crs, norm = ops.zeros(Lc.ny, self.lv[1].ld), ops.norm_slots()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
-        def time_pass(b, x_in, x_out):
+        t_begin = time.perf_counter()
+
+        def time_pass(b, x_in, x_out, crs=crs):
             ops.begin()
             for rep in range(3):  # the first launch is not timed
                 ops.smooth_fused(b, x_in, x_out, None, crs, L.nx, eng.lv[1].nx, L.t0, L.t1, L.fix_lo, L.fix_hi,
@@ -267,6 +271,8 @@ class SlabMultigrid:
                 gap = max(ms) > 1.06 * lo  # both kinds have been seen (they are 10 % or more apart)
                 if gap and len(fast) >= 4:
                     break
+                if len(ms) >= 4 and time.perf_counter() - t_begin > self.PLACE_BUDGET_SECONDS:
+                    break
         except torch.OutOfMemoryError:  # someone else took the memory meanwhile: choose among what there is
             torch.cuda.empty_cache()
         if len(ms) < 4:
@@ -288,26 +294,64 @@ class SlabMultigrid:
                 break
         final, ia, ib, ic = best
         pick = [pick[ia], pick[ib], pick[ic], pick[6 - ia - ib - ic]]
+        # Spread over stretches of the allocation sequence.  Measured with thirty candidates: the pass is fastest
+        # (by 2-4 % on top of the above) when the array it writes shares its stretch of ~96 GiB with neither of the
+        # two big arrays it reads -- b from the early stretch (the kind that is slow as an output reads as fast as any),
+        # the two x arrays from two different later stretches.  So: b := a candidate of the slow kind; one x := the
+        # fastest output; the other x := whichever of some candidates further along the sequence makes the fastest
+        # pair, timed in both directions as the cycle uses them.  Kept only if faster than the choice above.
+        spread = None
+        slow = [k for k in range(len(ms)) if ms[k] > 1.06 * min(ms)]
+        if gap and slow and len(arrs) < kmax:
+            n_timed = len(arrs)
+            try:
+                while (len(arrs) < min(kmax, n_timed + self.PLACE_SPREAD_CANDIDATES)
+                       and time.perf_counter() - t_begin < self.PLACE_BUDGET_SECONDS):
+                    arrs.append(ops.zeros(L.ny, L.ld))
+            except torch.OutOfMemoryError:
+                torch.cuda.empty_cache()
+            later = list(range(n_timed, len(arrs)))
+            xo, bk = pick[0], slow[0]
+            tried = []
+            for xi in [pick[1]] + later[len(later) // 2 :: 3] + later[-1:]:
+                if xi in tried or xi == xo:
+                    continue
+                tried.append(xi)
+                t = 0.5 * (time_pass(arrs[bk], arrs[xi], arrs[xo]) + time_pass(arrs[bk], arrs[xo], arrs[xi]))
+                combos += 1
+                if verbose:
+                    print(f"placement: b = candidate {bk}, x = candidates {xo} and {xi}: {t:.3f} ms", flush=True)
+                if spread is None or t < spread[0]:
+                    spread = (t, xi)
+            if spread is not None and spread[0] < 0.995 * final:
+                rk = next((k for k in slow[1:] + list(range(len(arrs))) if k not in (xo, spread[1], bk)))
+                final, pick = spread[0], [xo, spread[1], bk, rk]
         fin = [arrs[k] for k in pick]
         del arrs, xa, xb, bb
         torch.cuda.empty_cache()
+        self.placement = {"candidates": len(ms), "ms_as_output": [round(t, 3) for t in ms], "chosen": pick,
+                          "both_kinds_seen": gap, "ms_chosen_combination": round(final, 3), "combinations_timed": combos,
+                          "spread_over_the_allocation_sequence": spread is not None and pick[1] == spread[1] and pick[2] in slow}
+        # level 1's x is the correction the finest pass reads: its candidates are judged by both passes
+        xa1 = self._place_level1(cb, ev, lambda c: 0.5 * (time_pass(fin[2], fin[0], fin[1], c) + time_pass(fin[2], fin[1], fin[0], c)),
+                                 t_begin, verbose)
         for a in fin + [cb]:  # the timed launches left values behind: back to zero
             ops.zero_(a)
         ops.stream.synchronize()
-        self.placement = {"candidates": len(ms), "ms_as_output": [round(t, 3) for t in ms], "chosen": pick,
-                          "both_kinds_seen": gap, "ms_chosen_combination": round(final, 3), "combinations_timed": combos}
-        return fin, cb, self._place_level1(cb, ev, verbose)
+        return fin, cb, xa1
 
-    def _place_level1(self, b1, ev, verbose=False):
+    def _place_level1(self, b1, ev, finest_with, t_begin, verbose=False):
         """The same for the one other pass that writes gigabytes: level 1's ascent pass (its x, a quarter of the
-        finest array) takes 1.04 or 1.10 ms at 32769 x 32769 depending on the allocation it writes.  Up to eight
-        candidates are timed as its output (b = the level's right-hand side, which is kept); the fastest becomes the
-        level's x.  Only where that pass is the 9-stage one (recomputed pre-smoothing); None otherwise."""
+        finest array) takes 1.02 or 1.10 ms at 32769 x 32769 depending on the allocation it writes.  Up to eight
+        candidates are timed as its output (b = the level's right-hand side, which is kept) and as the correction the
+        finest pass reads (finest_with(candidate): ms of that pass on the arrays chosen for it); the one with the
+        smallest sum becomes the level's x.  Only where that pass is the 9-stage one (recomputed pre-smoothing); None
+        otherwise."""
         if self.n_para < 3 or not self._recomputed(1) or (self.world > 1 and self.n_dist < 2):
             return None
         eng, ops, L1, L2 = self, self.ops, self.lv[1], self.lv[2]
         crs = ops.zeros(L2.ny, L2.ld)
-        cands, ms = [], []
+        cands, ms, fin_ms = [], [], []
         try:
             for _ in range(8):
                 a = ops.zeros(L1.ny, L1.ld)
@@ -321,17 +365,21 @@ class SlabMultigrid:
                 ops.stream.synchronize()
                 cands.append(a)
                 ms.append(ev[0].elapsed_time(ev[1]) / 2)
-                if len(ms) >= 3 and max(ms) > 1.03 * min(ms) and sum(t <= 1.01 * min(ms) for t in ms) >= 2:
-                    break  # both kinds seen, and the fast one twice
+                fin_ms.append(finest_with(a))
+                if len(ms) >= 6 and max(ms) > 1.05 * min(ms) and sum(t <= 1.01 * min(ms) for t in ms) >= 2:
+                    break  # both kinds seen (they are 6-8 % apart), and the fast one twice
+                if time.perf_counter() - t_begin > self.PLACE_BUDGET_SECONDS + 0.5:
+                    break
         except torch.OutOfMemoryError:
             torch.cuda.empty_cache()
-        if not ms:
+        if not fin_ms:
             return None
-        k = min(range(len(ms)), key=lambda q: ms[q])
+        k = min(range(len(fin_ms)), key=lambda q: ms[q] + fin_ms[q])
         best = cands[k]
         ops.zero_(best)
         ops.stream.synchronize()
         self.placement["level1_ms_as_output"] = [round(t, 4) for t in ms]
+        self.placement["finest_ms_with_it_as_correction"] = [round(t, 3) for t in fin_ms]
         self.placement["level1_chosen"] = k
         del cands, crs
         torch.cuda.empty_cache()

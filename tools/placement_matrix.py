@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--knobs-only", action="store_true")
     ap.add_argument("--data", action="store_true")
     ap.add_argument("--scan", action="store_true")
+    ap.add_argument("--thirds", action="store_true", help="with --count 30: the roles x_in, x_out, b taken from the first, the "
+                    "second and the third dozen of the arrays (stretches of ~96 GiB of the process's allocations)")
     args = ap.parse_args()
     import torch
     from multigrid_amd.levels import make_plan
@@ -36,6 +38,9 @@ def main():
             A.append(ops.zeros(L.ny, L.ld))
         if k < args.coarse:
             C.append(ops.zeros(Lc.ny, Lc.ld))
+
+    if args.thirds:  # one more coarse array from the end of the sequence
+        C.append(ops.zeros(Lc.ny, Lc.ld))
 
     def t(b, xi, xo, crs, cb, reps=2):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -62,6 +67,29 @@ def main():
             out = [t(*others(k), k, 0, 1) for k in range(args.count)]
             print(f"{knob} {v:3d}: x_out = k:", " ".join(f"{v:.2f}" for v in out), flush=True)
         check(ops.L.mg_set_tuning(b"xcd_stagger", 0))
+    if args.thirds:
+        c = args.count
+        zone = {"A": [1, 2, 3], "B": [c // 3 + 2, c // 3 + 3, c // 3 + 4], "C": [c - 4, c - 3, c - 2]}
+        print("coarse right-hand side = the first coarse array (allocated at the start); zones: A = arrays", zone["A"], "B =", zone["B"],
+              "C =", zone["C"], flush=True)
+        for zb in "ABC":
+            for zi in "ABC":
+                row = []
+                for zo in "ABC":
+                    pick = {}
+                    used = []
+                    for role, z in (("b", zb), ("xi", zi), ("xo", zo)):
+                        k = next(j for j in zone[z] if j not in used)
+                        used.append(k)
+                        pick[role] = k
+                    row.append(f"x_out {zo}: {t(pick['b'], pick['xi'], pick['xo'], 1, 0):.3f}")
+                print(f"b in {zb}, x_in in {zi} | " + "  ".join(row), flush=True)
+        # the coarse right-hand side from the end of the sequence instead
+        last = len(C) - 1
+        for zo in "ABC":
+            k = zone[zo]
+            print(f"coarse right-hand side allocated last, b and x_in in {zo}, x_out {zo}: {t(k[0], k[1], k[2], 1, last):.3f}", flush=True)
+        return
     if args.scan:  # every array as the output, then as an input of a fast and of a slow output
         out = [t(*others(k), k, 0, 1) for k in range(args.count)]
         print("x_out = k:", " ".join(f"{v:.2f}" for v in out), flush=True)
