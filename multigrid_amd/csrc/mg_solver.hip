@@ -427,13 +427,8 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
         }
         if (ok) s->placement_candidates = nt, *cb_out = cb, cb = nullptr;
     }
-    // the candidates not chosen go back before the next level's are made
-    (void)hipStreamSynchronize(s->stream);
-    for (int k = 0; k < na; ++k)
-        if (a[k]) {
-            (void)hipFree(a[k]);
-            a[k] = nullptr;
-        }
+    // (the candidates not chosen are still held: the next level's candidates then come from further along the sequence of
+    // allocations, not from the memory these give back, which is the stretch the level's right-hand side lies in)
     // The same for the one other pass that writes gigabytes: level 1's ascent pass (1.04 or 1.10 ms at 32769 x 32769
     // depending on the allocation it writes its x into), where that is the 9-stage pass with recomputed
     // pre-smoothing.  Up to eight candidates are timed as its output beside the level's right-hand side (the array

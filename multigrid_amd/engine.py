@@ -327,14 +327,16 @@ class SlabMultigrid:
                 rk = next((k for k in slow[1:] + list(range(len(arrs))) if k not in (xo, spread[1], bk)))
                 final, pick = spread[0], [xo, spread[1], bk, rk]
         fin = [arrs[k] for k in pick]
-        del arrs, xa, xb, bb
-        torch.cuda.empty_cache()
         self.placement = {"candidates": len(ms), "ms_as_output": [round(t, 3) for t in ms], "chosen": pick,
                           "both_kinds_seen": gap, "ms_chosen_combination": round(final, 3), "combinations_timed": combos,
                           "spread_over_the_allocation_sequence": spread is not None and pick[1] == spread[1] and pick[2] in slow}
-        # level 1's x is the correction the finest pass reads: its candidates are judged by both passes
+        # level 1's x is the correction the finest pass reads: its candidates are judged by both passes.  They are
+        # allocated while the candidates above are still held, so that they come from further along the sequence and
+        # not from the memory the unchosen ones give back (which is the stretch the level's right-hand side lies in).
         xa1 = self._place_level1(cb, ev, lambda c: 0.5 * (time_pass(fin[2], fin[0], fin[1], c) + time_pass(fin[2], fin[1], fin[0], c)),
                                  t_begin, verbose)
+        del arrs, xa, xb, bb
+        torch.cuda.empty_cache()
         for a in fin + [cb]:  # the timed launches left values behind: back to zero
             ops.zero_(a)
         ops.stream.synchronize()
