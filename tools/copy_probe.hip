@@ -138,6 +138,14 @@ __global__ __launch_bounds__(256) void mix_tile_ahead(const double* __restrict__
     }
   }
 }
+// pseudo-random doubles in (-1, 1): does the rate depend on the data?
+__global__ __launch_bounds__(256) void fill_random(double* __restrict__ o, i64 n, unsigned long long seed) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    o[i] = (double)(long long)z * (1.0 / 9223372036854775808.0);
+  }
+}
 int main(int argc, char** argv) {
   i64 ny = 32768, ld = 32768 + 16;
   i64 n = ny * ld, n2 = n / 2;
@@ -150,7 +158,7 @@ int main(int argc, char** argv) {
     float best = 1e9, tot = 0; int reps = 5;
     for (int r = 0; r < reps; ++r) { CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms; if (ms < best) best = ms; }
-    printf("%-28s avg %7.3f ms  %7.0f GB/s   best %7.0f GB/s\n", name, tot / reps, bytes / (tot / reps) / 1e6, bytes / best / 1e6); fflush(stdout);
+    printf("%-58s avg %7.3f ms  %7.0f GB/s   best %7.0f GB/s\n", name, tot / reps, bytes / (tot / reps) / 1e6, bytes / best / 1e6); fflush(stdout);
   };
   for (int blocks : {2048, 4096, 8192, 65536}) {
     char nm[64]; snprintf(nm, 64, "copy_gs blocks=%d", blocks);
@@ -210,6 +218,53 @@ int main(int argc, char** argv) {
     // the same with the roles of the arrays exchanged: which allocation is written decides as much as the kernel
     report("mix_tile nt rpb=64, writes a", bytes, [&] { hipLaunchKernelGGL(mix_tile<true>, dim3(64 * 512), dim3(256), 0, 0, o, b, c, a, cbv, ld, cld, 64, 64, 512); });
     report("mix_tile nt rpb=64, writes b", bytes, [&] { hipLaunchKernelGGL(mix_tile<true>, dim3(64 * 512), dim3(256), 0, 0, o, a, c, b, cbv, ld, cld, 64, 64, 512); });
+  }
+  { // The same movers with their arrays spread over the process's sequence of allocations, as the solver's placement
+    // selection spreads the finest pass's arrays: 24 more arrays of the same size; "early" = among the first three
+    // (a, b, o above), "mid" and "late" = the 10th and the 22nd of the new ones.
+    double *c, *cbv; i64 cld = 16384 + 16, cn = 16384 * cld;
+    CK(hipMalloc(&c, cn * 8)); CK(hipMalloc(&cbv, cn * 8)); CK(hipMemset(c, 1, cn * 8)); CK(hipMemset(cbv, 0, cn * 8));
+    double* P[24]; int np = 0;
+    for (; np < 24; ++np) { if (hipMalloc(&P[np], n * 8) != hipSuccess) { (void)hipGetLastError(); break; } CK(hipMemset(P[np], 1, n * 8)); }
+    if (np >= 23) {
+      const double bytes = 28.0 * ny * 32768;
+      double *mid = P[10], *mid2 = P[11], *late = P[22];
+      struct { const char* nm; double *x, *b, *o; } cases[] = {
+        {"x early, b early, out early", a, b, o}, {"x early, b early, out mid", a, b, mid}, {"x mid, b mid, out mid", mid2, P[12], mid},
+        {"x late, b early, out mid", late, b, mid}, {"x mid, b early, out late", mid, b, late}, {"x early, b late, out mid", a, late, mid}};
+      for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) { // the same once more on pseudo-random data
+        for (double* q : {a, b, o, mid, mid2, late, P[12]}) hipLaunchKernelGGL(fill_random, dim3(65536), dim3(256), 0, 0, q, n, (unsigned long long)(size_t)q);
+        hipLaunchKernelGGL(fill_random, dim3(65536), dim3(256), 0, 0, c, cn, 77ull);
+        CK(hipDeviceSynchronize());
+        printf("--- pseudo-random data in every array\n");
+      }
+      for (auto& q : cases) {
+        char nm[96];
+        snprintf(nm, 96, "mix_flat nt: %s", q.nm);
+        report(nm, bytes, [&] { hipLaunchKernelGGL(mix_flat<true>, dim3(64 * (unsigned)(ny / 2)), dim3(256), 0, 0, q.x, q.b, c, q.o, cbv, ld, cld, 64); });
+        snprintf(nm, 96, "mix_tile nt 64: %s", q.nm);
+        report(nm, bytes, [&] { hipLaunchKernelGGL(mix_tile<true>, dim3(64 * 512), dim3(256), 0, 0, q.x, q.b, c, q.o, cbv, ld, cld, 64, 64, 512); });
+      }
+      }
+    }
+    if (np >= 23) { // how far ahead must the loads run when only two waves per SIMD are resident (as in the fused finest pass)?
+      const double bytes = 28.0 * ny * 32768;
+      const size_t lds = 72 * 1024; // two workgroups of four waves per CU
+      CK(hipFuncSetAttribute((const void*)mix_tile_ahead<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      CK(hipFuncSetAttribute((const void*)mix_tile_ahead<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      CK(hipFuncSetAttribute((const void*)mix_tile_ahead<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      CK(hipFuncSetAttribute((const void*)mix_tile_ahead<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      CK(hipFuncSetAttribute((const void*)mix_tile_ahead<true, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      double *xx = P[22], *bb = b, *oo = P[10];
+      report("2 waves/SIMD, loads 2 rows ahead", bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<true, 2>), dim3(64 * 512), dim3(256), lds, 0, xx, bb, c, oo, cbv, ld, cld, 64, 64, 512); });
+      report("2 waves/SIMD, loads 4 rows ahead", bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<true, 4>), dim3(64 * 512), dim3(256), lds, 0, xx, bb, c, oo, cbv, ld, cld, 64, 64, 512); });
+      report("2 waves/SIMD, loads 6 rows ahead", bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<true, 6>), dim3(64 * 480), dim3(256), lds, 0, xx, bb, c, oo, cbv, ld, cld, 60, 64, 480); });
+      report("2 waves/SIMD, loads 8 rows ahead", bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<true, 8>), dim3(64 * 512), dim3(256), lds, 0, xx, bb, c, oo, cbv, ld, cld, 64, 64, 512); });
+      report("2 waves/SIMD, loads 12 rows ahead", bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<true, 12>), dim3(64 * 512), dim3(256), lds, 0, xx, bb, c, oo, cbv, ld, cld, 60, 64, 512); });
+      report("all waves resident, loads 4 rows ahead", bytes, [&] { hipLaunchKernelGGL((mix_tile_ahead<true, 4>), dim3(64 * 512), dim3(256), 0, 0, xx, bb, c, oo, cbv, ld, cld, 64, 64, 512); });
+    }
+    for (int k = 0; k < np; ++k) CK(hipFree(P[k]));
   }
   { // Does a read that follows a write of the same data closely find it in the Infinity Cache?  One array is written
     // and read back band by band (a write launch, then a read launch of the same band), for several band sizes;
