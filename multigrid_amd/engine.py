@@ -49,7 +49,7 @@ class SlabMultigrid:
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
                  store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
                  recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=False,
-                 overlap_min_rows=4096, batch_stop="max", fine_smoother="jacobi"):
+                 overlap_min_rows=4096, batch_stop="max", fine_smoother="jacobi", comm=None):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -96,7 +96,9 @@ class SlabMultigrid:
             warnings.warn(f"the first whole-domain level ({W0.ny} x {W0.nx}) does not fit LDS: its SSOR wavefront will walk "
                           "global memory, an order of magnitude slower per step; use more Jacobi levels "
                           "(levels.choose_n_para) or coarse_ordering='redblack'")
-        self.comm = SlabComm(ops, group, world, rank)
+        # comm: an object with SlabComm's interface in its place (tools/rank_rehearsal.py runs one rank of an
+        # N-rank job alone on one GPU that way, with the rank as its own neighbours)
+        self.comm = comm if comm is not None else SlabComm(ops, group, world, rank)
         self.n_para = n_para
         self.epsilon = epsilon
         self.coarse_ordering = coarse_ordering

@@ -82,7 +82,9 @@ class HipOps:
     @contextlib.contextmanager
     def comm_side(self, after=None):
         if self._comm is None:
-            self._comm = torch.cuda.Stream(self.device)
+            # high priority: the few workgroups of an exchange must not queue behind the thousands of the
+            # interior launch they run beside (measured: 550 us instead of 70 for the same rows otherwise)
+            self._comm = torch.cuda.Stream(self.device, priority=-1)
         self._comm.wait_event(after if after is not None else self.mark())
         self._on_comm = True
         try:

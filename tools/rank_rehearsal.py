@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""One rank of an N-rank weak-scaling job, alone on one GPU, with the rank as its own neighbours.
+
+The multi-GPU engine cuts the grid into row slabs; what a rank does per V-cycle -- its passes (cut into
+interior and slab ends around the halo exchange), the exchange rounds, the all-gather of the first
+replicated level's right-hand side, the replicated levels, the MAX-reduction of the norm -- does not depend
+on what the neighbours' rows contain.  This tool builds rank `--rank` of `--world` ranks exactly as
+`bench.py --gpus N` builds it (same slab, same number of distributed levels, same halo depth, same
+placement selection) and replaces the communicator by one that moves the same rows between the same
+buffers ON THIS DEVICE:
+
+  --comm rccl   (default) the engine's own torch.distributed calls on a one-rank `nccl` group, every peer
+                mapped to rank 0: RCCL's host time per round and its copy kernels are the real ones, the
+                bytes cross HBM instead of xGMI;
+  --comm copy   plain device copies on the stream the exchange would run on (no RCCL in the process).
+
+Numbers are meaningless (the halo rows hold the rank's own rows); times are not: the cycle time here is
+what one rank's GPU and host need when the links cost nothing, i.e. t(1 rank) / t(this) is the ceiling of
+the weak-scaling efficiency that the slab engine's own overheads allow.  Prints one JSON line.
+
+    python tools/rank_rehearsal.py --world 8 --rank 3 --steps 10
+    rocprofv3 --kernel-trace --output-format csv -d out -- python3 tools/rank_rehearsal.py --world 8 --rank 3
+"""
+import argparse
+import json
+import os
+import socket
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=None, help="default: a middle rank (two neighbours)")
+    ap.add_argument("--exp", dest="n", type=int, default=14)
+    ap.add_argument("--jacobi-levels", dest="n_para", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "copy"])
+    ap.add_argument("--no-tune-placement", action="store_true")
+    ap.add_argument("--solve-order", action="store_true",
+                    help="read every cycle's norm before the next cycle is issued, as solve() must")
+    ap.add_argument("--overlap-min-rows", type=int, default=4096)
+    ap.add_argument("--dist-min-rows", type=int, default=None)
+    ap.add_argument("--rccl-high-priority", action="store_true", help="RCCL's own streams at high priority")
+    ap.add_argument("--engine-args", default="{}", help="JSON dict of further SlabMultigrid keyword arguments")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from multigrid_amd.comm import SlabComm
+    from multigrid_amd.engine import SlabMultigrid
+    from multigrid_amd.levels import choose_n_para
+    from multigrid_amd.ops import HipOps
+
+    world = args.world
+    rank = world // 2 if args.rank is None else args.rank
+    torch.cuda.set_device(0)
+    if args.comm == "rccl":
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True) if args.rccl_high_priority else None
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), pg_options=opts)
+
+    class LoopbackComm(SlabComm):
+        """SlabComm of rank `rank` of `world`, every peer being this process."""
+
+        def __init__(self, ops):
+            self.ops, self.group, self.world, self.rank = ops, None, world, rank
+            self.staged, self.rounds = False, 0
+            self.rccl = args.comm == "rccl"
+            if self.rccl:
+                t = ops.zeros(1, 1)
+                self.allreduce_max(t.view(-1))
+
+        def _peer(self, r):
+            return 0
+
+        def prepare(self, sends, recvs):
+            # what I send up is shaped like what comes from below, and the other way round
+            assert sorted(t.numel() for t, _ in sends) == sorted(t.numel() for t, _ in recvs) or world == 1 or \
+                rank in (0, world - 1)
+            if self.rccl:
+                n = min(len(sends), len(recvs))  # an end rank has one neighbour: equally many each way
+                return SlabComm.prepare(self, sends[:n], recvs[:n])
+            pairs = []
+            rs = list(recvs)
+            for t, _ in sends:
+                k = next((i for i, (u, _) in enumerate(rs) if u.numel() == t.numel()), None)
+                if k is not None:
+                    pairs.append((rs.pop(k)[0], t))
+            return ("copy", pairs)
+
+        def run(self, batch):
+            if batch[0] != "copy":
+                return SlabComm.run(self, batch)
+            if not batch[1]:
+                return
+            self.rounds += 1
+            with self.ops.ctx():
+                for dst, src in batch[1]:
+                    dst.copy_(src)
+
+        def allgather_rows(self, out, inp):
+            self.rounds += 1
+            R = inp.shape[0]
+            own = out[rank * R : (rank + 1) * R]
+            with self.ops.ctx():
+                if self.rccl:
+                    dist.all_gather_into_tensor(own.view(-1), inp.view(-1))
+                else:
+                    own.copy_(inp)
+                for q in range(world):  # the other ranks' rows: written once more on this device
+                    if q != rank:
+                        out[q * R : (q + 1) * R].copy_(own)
+
+        def allreduce_max(self, t):
+            if self.rccl:
+                with self.ops.ctx():
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t
+
+    n = args.n
+    gnx = 2 ** (n + 1) + 1
+    gny = world * 2 ** (n + 1) + 1
+    n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=max(1, n - 4))
+    h = 20.0 / 2 ** (n + 1)
+    ops = HipOps()
+    comm = LoopbackComm(ops) if world > 1 else None
+    extra = json.loads(args.engine_args)
+    eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, ops=ops, world=world, rank=rank, comm=comm, eager_dead_levels=True,
+                        tune_placement=not args.no_tune_placement, overlap_min_rows=args.overlap_min_rows,
+                        dist_min_rows=args.dist_min_rows, **extra)
+    import bench
+    bench.fill_rhs(eng, torch, n, rank)
+    torch.cuda.synchronize()
+
+    def run(k):
+        if not args.solve_order:
+            return eng.cycles(k)
+        errs = []
+        eng.ops.begin()
+        for _ in range(k):
+            eng._run_cycle()
+            errs.append(eng._global_err())
+        eng._flush_pending()
+        eng.ops.end()
+        return errs
+
+    eng.presmooth()
+    run(args.warmup)
+    torch.cuda.synchronize()
+    r0 = comm.rounds if comm else 0
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rounds = ((comm.rounds - r0) / args.steps) if comm else 0
+    # host time to issue one cycle: the same cycles again, the clock stopped before the device is waited for
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.ops.begin()
+    for _ in range(args.steps):
+        eng._run_cycle()
+        eng._reduce_err()
+    t_issue = time.perf_counter() - t0
+    eng._flush_pending()
+    eng.ops.end()
+    torch.cuda.synchronize()
+    out = {"world": world, "rank": rank, "comm": args.comm, "grid": [gny, gnx], "n_para": n_para,
+           "distributed_levels": eng.n_dist if world > 1 else None, "halo_rows": eng.plan.halo,
+           "ms_per_cycle": 1e3 * dt / args.steps, "order": "solve" if args.solve_order else "cycles",
+           "host_issue_ms_per_cycle": 1e3 * t_issue / args.steps,
+           "rounds_per_cycle": rounds,
+           "passes_cut": eng.split_passes, "placement_seconds": round(eng.placement_seconds, 2),
+           "placement": eng.placement}
+    print(json.dumps(out), flush=True)
+    eng.close()
+    if args.comm == "rccl":
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
