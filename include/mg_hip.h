@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 6
+#define MG_ABI_VERSION 7
 
 /* flags for the stencil entry points */
 #define MG_FLAG_FINEST 1 /* marks the launches of the finest level; ignored (large outputs get an instantiation of their own, see "stream_min_mib") */
@@ -186,6 +186,15 @@ int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out,
                              double h, double omega, uint64_t *norm_slots, int64_t norm_stride, double *coarse_b, int64_t cbny, int64_t cbnx,
                              int64_t cbld, int64_t T0, int64_t T1, int64_t nbatch, int64_t bstride,
                              int64_t cstride, int64_t cbstride, void *stream);
+/*
+ * The next mg_smooth_fused / mg_smooth_fused_restrict call of the calling host thread produces the rows
+ * j2 <= j < j3 as well (j1 <= j2; with a fused restriction also the coarse rows T2 <= T < T3, T1 <= T2, centred on
+ * rows of that range), in the same launch and with the same values as a second call with those ranges would.
+ * The setting is consumed by that one call, whether it succeeds or not.  For the two ends of a row slab, which a
+ * pass cut around its halo exchange produces after the interior rows (the slab layout that replaces the four
+ * blocks of core/parallel_multigrid.py:39-56): one launch instead of two.
+ */
+int mg_fused_also_rows(int64_t j2, int64_t j3, int64_t T2, int64_t T3);
 /* Tuning knobs of mg_smooth_fused: column pairs per lane (1 or 2), rows per tile (0 = automatic). */
 int mg_set_fused_tuning(int unroll, int rows);
 

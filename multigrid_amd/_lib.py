@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MG_HIP_LIB: another build of the library (A/B experiments with tools/); the default is the one beside this file
 LIB_PATH = os.environ.get("MG_HIP_LIB") or os.path.join(_HERE, "libmg_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 NORM_SLOTS = 64
 FLAG_FINEST = 1
 SOR_LEXICOGRAPHIC = 0
@@ -45,6 +45,7 @@ SIGNATURES = {
     "mg_smooth_fused": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _n, _d, _d, _p, _i, _i, _i, _p], _n),
     "mg_smooth_fused_restrict": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _d, _d, _p, _i, _p, _i, _i,
                                   _i, _i, _i, _i, _i, _i, _i, _p], _n),
+    "mg_fused_also_rows": ([_i, _i, _i, _i], _n),
     "mg_set_fused_tuning": ([_n, _n], _n),
     "mg_sor": ([_p, _p, _p, _i, _i, _i, _d, _i, _n, _n, _i, _i, _p], _n),
     "mg_gauss_seidel_rb": ([_p, _p, _i, _i, _i, _i, _i, _d, _n, _i, _i, _p], _n),

@@ -44,6 +44,20 @@ extern "C" int mg_set_fused_tuning(int unroll, int rows)
     return 0;
 }
 
+// A second row range for the next fused pass of the calling thread (mg_fused_also_rows): consumed by that call,
+// whether it succeeds or not.
+static thread_local i64 t_also[4];
+static thread_local bool t_also_set = false;
+
+extern "C" int mg_fused_also_rows(i64 j2, i64 j3, i64 T2, i64 T3)
+{
+    MG_REQUIRE(j2 >= 0 && j2 <= j3 && T2 >= 0 && T2 <= T3, "mg_fused_also_rows: bad ranges [%lld, %lld), [%lld, %lld)", (long long)j2,
+               (long long)j3, (long long)T2, (long long)T3);
+    t_also[0] = j2, t_also[1] = j3, t_also[2] = T2, t_also[3] = T3;
+    t_also_set = true;
+    return 0;
+}
+
 // the instantiations live in mg_fused_inst_*.hip
 extern template int pick_mode<1, false>(const FusedArgs &, bool, bool, bool, bool, hipStream_t);
 extern template int pick_mode<2, false>(const FusedArgs &, bool, bool, bool, bool, hipStream_t);
@@ -66,6 +80,11 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
                              i64 cbny, i64 cbnx, i64 cbld, i64 T0, i64 T1, i64 nbatch, i64 bstride, i64 cstride,
                              i64 cbstride, void *stream)
 {
+    i64 j2 = 0, j3 = 0, T2 = 0, T3 = 0;
+    if (t_also_set) {
+        j2 = t_also[0], j3 = t_also[1], T2 = t_also[2], T3 = t_also[3];
+        t_also_set = false;
+    }
     MG_REQUIRE(b && (x_out || coarse_b), "mg_smooth_fused: null array");
     MG_REQUIRE(nbatch >= 1 && nbatch <= 65535, "mg_smooth_fused: nbatch %lld outside 1..65535", (long long)nbatch);
     MG_REQUIRE(nbatch == 1 || (bstride >= ny * ld && bstride % 2 == 0 && (!crs || cstride >= cny * cld) &&
@@ -86,6 +105,8 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
                "mg_smooth_fused: arrays must be 16-byte aligned with an even leading dimension");
     MG_REQUIRE(j0 >= 0 && j1 <= ny && j0 <= j1, "mg_smooth_fused: row range [%lld, %lld) outside the array", (long long)j0,
                (long long)j1);
+    MG_REQUIRE(j2 == j3 || (j2 >= j1 && j3 <= ny), "mg_smooth_fused: second row range [%lld, %lld) must follow the first inside the array",
+               (long long)j2, (long long)j3);
     MG_REQUIRE((!x_out || (x_in != x_out && r != x_out)) && (!r || (const double *)r != x_in),
                "mg_smooth_fused: aliased arrays");
     MG_REQUIRE(nx < ((i64)1 << 30) && ny < ((i64)1 << 30), "mg_smooth_fused: grid side too large");
@@ -95,7 +116,7 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
         MG_REQUIRE(ofst_j <= 0, "mg_smooth_fused: ofst_j must be <= 0");
         // every fine cell of the produced rows must have its coarse cells: 1 <= t - ofst_j <= 2*cny-3,
         // 1 <= c <= 2*cnx-3 (rows beyond, read only for the halo of the pipeline, are clamped)
-        MG_REQUIRE(j0 - ofst_j >= 1 && j1 - 1 - ofst_j <= 2 * cny - 3 && nx - 2 <= 2 * cnx - 3,
+        MG_REQUIRE(j0 - ofst_j >= 1 && (j3 > j2 ? j3 : j1) - 1 - ofst_j <= 2 * cny - 3 && nx - 2 <= 2 * cnx - 3,
                    "mg_smooth_fused: coarse grid %lld x %lld does not cover the fine rows", (long long)cny,
                    (long long)cnx);
     }
@@ -113,11 +134,19 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
                                 2 * (T1 - 1) + ofst_j + 1 <= ny - 1),
                    "mg_smooth_fused_restrict: coarse rows [%lld, %lld) are not centred on the produced fine rows",
                    (long long)T0, (long long)T1);
+        MG_REQUIRE(T2 == T3 || (j2 < j3 && T2 >= T1 && T3 <= cbny - 1 && 2 * T2 + ofst_j >= j2 && 2 * (T3 - 1) + ofst_j < j3 &&
+                                2 * (T3 - 1) + ofst_j + 1 <= ny - 1),
+                   "mg_smooth_fused_restrict: coarse rows [%lld, %lld) of the second range are not centred on its fine rows",
+                   (long long)T2, (long long)T3);
+    } else {
+        T2 = T3 = 0;
     }
+    if (j0 == j1 && j2 < j3) j0 = j2, j1 = j3, T0 = T2, T1 = T3, j2 = j3 = 0, T2 = T3 = 0; // only the second range has rows
     if (j0 == j1) return 0;
     FusedArgs a;
     a.b = b, a.xin = x_in, a.xout = x_out, a.r = r, a.crs = crs;
     a.ny = ny, a.nx = nx, a.ld = ld, a.cny = cny, a.cnx = cnx, a.cld = cld;
+    a.j2 = j2, a.j3 = j3, a.T2 = T2, a.T3 = T3, a.nrc1 = 0;
     a.j0 = j0, a.j1 = j1, a.flo = fix_lo, a.fhi = fix_hi, a.oj = (int)ofst_j;
     a.h2 = h * h, a.hh = 1 / (h * h), a.om = omega, a.norm = (u64 *)norm_slots, a.norm_stride = norm_stride;
     a.rpb = a.ncb = a.nrc = a.ntc = a.stagger = a.lockstep = 0;

@@ -14,6 +14,9 @@ struct FusedArgs {
     const double *crs;   // coarse x to prolong and add before the sweeps (PROLONG)
     i64 ny, nx, ld, cny, cnx, cld;
     i64 j0, j1;          // rows to produce
+    i64 j2, j3;          // a second range of rows produced by the same launch (j2 == j3: none), with its coarse rows T2, T3
+    i64 T2, T3;
+    int nrc1;            // row chunks of the first range; the chunks from nrc1 on belong to the second
     i64 flo, fhi;        // rows <= flo and >= fhi are fixed (Dirichlet): passed through
     int rpb, ncb, nrc, ntc, oj, stagger;
     int lockstep;        // > 0: the waves of a workgroup meet at a barrier every `lockstep` groups of six rows
@@ -129,8 +132,13 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
         ic[g][0] = c0[g] >= 1 && c0[g] <= nx - 2;
         ic[g][1] = c0[g] + 1 >= 1 && c0[g] + 1 <= nx - 2;
     }
-    const int rb = (int)a.j0 + rc * a.rpb;
-    const int re = rb + a.rpb < (int)a.j1 ? rb + a.rpb : (int)a.j1;
+    // the launch may cover two row ranges (both ends of a slab in one launch): uniform per workgroup
+    const bool second = rc >= a.nrc1;
+    const int jhi = (int)(second ? a.j3 : a.j1);
+    const int Tlo = (int)(second ? a.T2 : a.T0), Thi = (int)(second ? a.T3 : a.T1);
+    const int rb = (int)(second ? a.j2 : a.j0) + (second ? rc - a.nrc1 : rc) * a.rpb;
+    const int re = rb + a.rpb < jhi ? rb + a.rpb : jhi;
+    (void)Tlo, (void)Thi;
     u64 nmax = 0;
 
     if (active && rb < re) { // uniform per wave
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(256) void mg_fused_kernel(const FusedArgs a0)
                             const int ctr = row - 1;
                             if (ctr >= rb && ctr < re && ((ctr - oj) & 1) == 0) {
                                 const int T = (ctr - oj) >> 1;
-                                if (T >= (int)a.T0 && T < (int)a.T1) {
+                                if (T >= Tlo && T < Thi) {
 #pragma unroll
                                     for (int g = 0; g < U; ++g) {
                                         const double a_right = rw[A1][g][1] / 8 + (rw[A2][g][1] + rw[A0][g][1]) / 16;
@@ -596,12 +604,15 @@ int launch_fused(FusedArgs a, hipStream_t st)
         rpb = D <= 5 ? g_fused_rows_shallow : (D >= 9 ? g_fused_rows_deep : 64); // the 9-sweep pass streams 9 extra rows per tile end: taller tiles
         // a small level cannot fill the chip, and its pass lasts as long as one wave needs for one tile:
         // shorter tiles (down to g_fused_min_rows) cut that time; the extra overlap rows cost nothing there
-        while (rpb > g_fused_min_rows && (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb) * a.nbatch < g_fused_min_blocks) rpb >>= 1;
+        while (rpb > g_fused_min_rows &&
+               (i64)a.ncb * ((a.j1 - a.j0 + rpb - 1) / rpb + (a.j3 - a.j2 + rpb - 1) / rpb) * a.nbatch < g_fused_min_blocks)
+            rpb >>= 1;
     }
     a.rpb = rpb;
     a.stagger = g_xcd_stagger < 0 ? a.ncb / 8 : g_xcd_stagger;
     a.lockstep = g_fused_lockstep;
-    a.nrc = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
+    a.nrc1 = (int)((a.j1 - a.j0 + rpb - 1) / rpb);
+    a.nrc = a.nrc1 + (int)((a.j3 - a.j2 + rpb - 1) / rpb);
     const dim3 grid((unsigned)(a.ncb * a.nrc), (unsigned)a.nbatch), block(64 * wpb);
     const size_t lds = DK >= 5 ? (size_t)wpb * ((DK + 1) / 3 + 1) * 3 * W * sizeof(double) : 0;
     bool launched = false;

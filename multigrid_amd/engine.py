@@ -519,7 +519,8 @@ class SlabMultigrid:
 
     def _pass(self, l, D, items, launch):
         """One fused pass over level l that reads D rows beyond the rows it produces, after the halo exchange
-        `items`.  launch(j0, j1) enqueues the pass for local rows j0 <= j < j1."""
+        `items`.  launch(j0, j1) enqueues the pass for local rows j0 <= j < j1; launch(j0, j1, (j2, j3)) for those
+        and the rows j2 <= j < j3 in one launch."""
         L = self.lv[l]
         if not items or not self._overlaps(l, D):
             if items:
@@ -536,8 +537,11 @@ class SlabMultigrid:
         with self.ops.comm_side(ready):
             self._exchange(items)
         self.ops.comm_join()
-        launch(L.t0, a)
-        launch(e, L.t1)
+        if getattr(self.ops, "supports_also_rows", False):
+            launch(L.t0, a, (e, L.t1))  # both slab ends in one launch
+        else:
+            launch(L.t0, a)
+            launch(e, L.t1)
 
     @staticmethod
     def _cut(L, D):
@@ -579,6 +583,11 @@ class SlabMultigrid:
         def crows(j0, j1):  # the coarse rows a launch over fine rows j0 .. j1-1 restricts into
             return (Lc.t0, Lc.t1) if (j0, j1) == (L.t0, L.t1) else self._coarse_rows(Lc, H, j0, j1)
 
+        def also_kw(also, restricts):  # a second row range of the same launch (the other slab end), with its coarse rows
+            if also is None:
+                return {}
+            return {"also_rows": (*also, *(crows(*also) if restricts else (0, 0)))}
+
         def after_restriction():  # the next level's right-hand side has been produced
             if to_rep:
                 self._allgather_b(l + 1)
@@ -595,9 +604,9 @@ class SlabMultigrid:
             if src is None:  # descent: only the restricted residual leaves the pass
                 assert restrict and crs is None
 
-                def launch(j0, j1):
+                def launch(j0, j1, also=None):
                     o.smooth_fused(self.b[l], None, None, r, None, L.nx, cnx, j0, j1, L.fix_lo, L.fix_hi, L.oj, n, L.h,
-                                   norm, cb, Lc.nx, *crows(j0, j1), omega=self.jacobi_omega)
+                                   norm, cb, Lc.nx, *crows(j0, j1), omega=self.jacobi_omega, **also_kw(also, True))
                 self._pass(l, n + 2, pend, launch)
                 after_restriction()
                 return None
@@ -606,9 +615,9 @@ class SlabMultigrid:
             assert crs is not None and not restrict and not pend
             items = [(crs, self.lv[l + 1], (self.N1 + n) // 2 + 2)] if (dist_ and not crs_has_halo) else []
 
-            def launch(j0, j1):
+            def launch(j0, j1, also=None):
                 o.smooth_fused(self.b[l], None, xa, r, crs, L.nx, cnx, j0, j1, L.fix_lo, L.fix_hi, L.oj, self.N1 + n, L.h,
-                               norm, prolong_after=self.N1, omega=self.jacobi_omega)
+                               norm, prolong_after=self.N1, omega=self.jacobi_omega, **also_kw(also, False))
             self._pass(l, self.N1 + n + (1 if r is not None else 0), items, launch)
             return xa
         if self.fused:
@@ -626,13 +635,15 @@ class SlabMultigrid:
                 if last and norm is not None:
                     o.norm_reset(norm)
                 if last and restrict:
-                    def launch(j0, j1, src=src, dst=dst, first=first, k=k):
+                    def launch(j0, j1, also=None, src=src, dst=dst, first=first, k=k):
                         o.smooth_fused(self.b[l], src, dst, r, crs if first else None, L.nx, cnx, j0, j1, L.fix_lo,
-                                       L.fix_hi, L.oj, k, L.h, norm, cb, Lc.nx, *crows(j0, j1), omega=self.jacobi_omega)
+                                       L.fix_hi, L.oj, k, L.h, norm, cb, Lc.nx, *crows(j0, j1), omega=self.jacobi_omega,
+                                       **also_kw(also, True))
                 else:
-                    def launch(j0, j1, src=src, dst=dst, first=first, last=last, k=k):
+                    def launch(j0, j1, also=None, src=src, dst=dst, first=first, last=last, k=k):
                         o.smooth_fused(self.b[l], src, dst, r if last else None, crs if first else None, L.nx, cnx, j0,
-                                       j1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None, omega=self.jacobi_omega)
+                                       j1, L.fix_lo, L.fix_hi, L.oj, k, L.h, norm if last else None, omega=self.jacobi_omega,
+                                       **also_kw(also, False))
                 self._pass(l, depth, items, launch)
                 src = dst
             if restrict:

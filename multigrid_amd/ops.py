@@ -29,6 +29,7 @@ class HipOps:
         self._side, self._on_side, self._side_pending = None, False, False
         self._copy = None
         self._comm, self._on_comm, self._comm_done = None, False, None
+        self._cap, self._cap_swap = None, None
 
     # ---- memory / stream plumbing (torch) -------------------------------------------------
     def zeros(self, rows, ld, batch=None):
@@ -82,9 +83,7 @@ class HipOps:
     @contextlib.contextmanager
     def comm_side(self, after=None):
         if self._comm is None:
-            # high priority: the few workgroups of an exchange must not queue behind the thousands of the
-            # interior launch they run beside (measured: 550 us instead of 70 for the same rows otherwise)
-            self._comm = torch.cuda.Stream(self.device, priority=-1)
+            self._comm = torch.cuda.Stream(self.device)
         self._comm.wait_event(after if after is not None else self.mark())
         self._on_comm = True
         try:
@@ -175,13 +174,18 @@ class HipOps:
     supports_fused = True
     supports_prolong_after = True
 
+    supports_also_rows = True
+
     def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
-                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0, omega=1.0):
+                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0, omega=1.0, also_rows=None):
         """[x_in += P(crs)] -> `sweeps` Jacobi sweeps -> [residual] -> [restriction into coarse_b];
         x_in None = start from zero; x_out None (with coarse_b) = x is not stored; prolong_after = n:
         the prolongation is added after the first n sweeps (from zero) instead of before the first;
-        omega < 1: damped sweeps, x + omega * (t - x)."""
+        omega < 1: damped sweeps, x + omega * (t - x).  also_rows = (j2, j3, T2, T3): the same launch
+        also produces rows j2 .. j3-1 (and restricts into coarse rows T2 .. T3-1)."""
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        if also_rows is not None:
+            check(self.L.mg_fused_also_rows(*also_rows))
         self._same_layout(b, x_in, x_out, r)
         nb, bs, ny, ld = self._nb(b)
         _, cs, cny, cld = self._nb(crs) if crs is not None else (1, 0, 0, 0)
@@ -256,11 +260,39 @@ class HipOps:
     supports_graphs = True
 
     def graph_begin(self):
-        check(self.L.mg_graph_begin(self._s))
+        """Start recording the calls that follow into a graph instead of running them.  They are recorded on a
+        stream of their own that stands in for the current one (main or side) until graph_end(): in a process
+        that holds an RCCL communicator, torch's watchdog thread polls the end events of outstanding collectives,
+        and on this HIP runtime such a poll fails with hipErrorCapturedEvent -- and takes the process down --
+        while a stream that has waited for one of those events is capturing (tools/rccl_capture_probe.py).  A
+        stream that never waits for anything but this object's own events is safe; a graph can be launched on
+        any stream."""
+        if self._cap is None:
+            self._cap = torch.cuda.Stream(self.device)
+        assert self._cap_swap is None, "graph captures do not nest"
+        if self._on_side:
+            self._cap_swap = ("_side", self._side)
+            self._side = self._cap
+        else:
+            self._cap_swap = ("stream", self.stream)
+            self.stream = self._cap
+        try:
+            check(self.L.mg_graph_begin(self._s))
+        except Exception:
+            self._graph_restore()
+            raise
+
+    def _graph_restore(self):
+        name, stream = self._cap_swap
+        setattr(self, name, stream)
+        self._cap_swap = None
 
     def graph_end(self):
         g = C.c_void_p()
-        check(self.L.mg_graph_end(self._s, C.byref(g)))
+        try:
+            check(self.L.mg_graph_end(self._s, C.byref(g)))
+        finally:
+            self._graph_restore()
         return g
 
     def graph_launch(self, g):

@@ -5,6 +5,15 @@ import socket
 import time
 
 
+def rank_watchdog(seconds=150):
+    """Call first in a spawned rank: if the rank is still running after `seconds`, every thread's stack goes to
+    stderr and the process exits, so that a deadlock among ranks fails its test with the place each rank waits at
+    instead of hanging until the test's own time limit."""
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(seconds, exit=True, file=sys.stderr)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -129,10 +129,22 @@ class OracleOps:
 
     supports_fused = True
     supports_prolong_after = True
+    supports_also_rows = True
+
+    def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
+                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0, omega=1.0, also_rows=None):
+        """also_rows = (j2, j3, T2, T3): a second row range of the same pass, here simply a second pass."""
+        self._smooth_fused(b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm, coarse_b, cbnx, T0, T1,
+                           prolong_after, omega)
+        if also_rows is not None:
+            j2, j3, T2, T3 = also_rows
+            self.also_rows_calls = getattr(self, "also_rows_calls", 0) + 1
+            self._smooth_fused(b, x_in, x_out, r, crs, nx, cnx, j2, j3, fix_lo, fix_hi, oj, sweeps, h, norm, coarse_b, cbnx, T2, T3,
+                               prolong_after, omega)
 
     @_batched
-    def smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
-                     coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0, omega=1.0):
+    def _smooth_fused(self, b, x_in, x_out, r, crs, nx, cnx, j0, j1, fix_lo, fix_hi, oj, sweeps, h, norm=None,
+                      coarse_b=None, cbnx=0, T0=0, T1=0, prolong_after=0, omega=1.0):
         """The fused pass as the sequence it stands for: prolong_add (before the first sweep, or after
         `prolong_after` sweeps from zero), `sweeps` Jacobi sweeps, residual (rows between the fixed rows
         are the interior; only rows j0..j1-1 are written back)."""

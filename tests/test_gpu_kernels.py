@@ -776,3 +776,90 @@ def _fused_vs_oracle(L, shape, mode):
         assert nrm.value == np.abs(r_want[1:-1, 1:-1]).max()
     if restrict:
         assert np.array_equal(cb[:, :cnx].cpu().numpy(), cb_want)
+
+
+@pytest.mark.parametrize("shape", [(130, 1001), (300, 257), (600, 2051)], ids=str)
+@pytest.mark.parametrize("mode", ["finest", "descent_no_x", "ascent", "nine_stage"])
+@pytest.mark.parametrize("rows", [0, 8])
+def test_fused_pass_two_row_ranges_in_one_launch(L, shape, mode, rows):
+    """mg_fused_also_rows: the next fused pass produces a second row range in the same launch (the two ends of a
+    slab whose interior rows were launched before the halo exchange).  Equal, bit for bit, to two launches; the
+    setting is consumed by one call; a second range in front of the first is rejected."""
+    import ctypes as C
+    import torch
+    ny, nx = shape
+    rng = np.random.default_rng(ny + 5 * nx)
+    h, oj = 0.3, -1
+    x, b = rng.standard_normal(shape), rng.standard_normal(shape)
+    cny, cnx = (ny - 2) // 2 + 2, (nx - 1) // 2 + 1
+    c = rng.standard_normal((cny, cnx))
+    flo, fhi = 1, ny - 1
+    # the ends of a "slab": rows [2, a) and [e, ny - 1); odd cuts = fine centres of coarse rows (2T + oj, oj = -1)
+    a, e = 2 + 2 * 9 + 1, ny - 1 - 2 * 10
+    assert a % 2 == 1 and e % 2 == 1 and a < e
+
+    def crows(j0, j1):  # coarse rows whose fine centre 2T + oj lies in [j0, j1)
+        return -(-(j0 - oj) // 2), -(-(j1 - oj) // 2)
+
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    db, dx, dc = padded(b), padded(x), padded(c)
+    ld = db.stride(0)
+    L.check(lib.mg_set_fused_tuning(2, rows))
+
+    def run(ranges, also):
+        out, rr, cb = padded(np.full(shape, 7.0)), padded(np.zeros(shape)), padded(np.full((cny, cnx), 3.0))
+        slots = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
+        for k, (j0, j1) in enumerate(ranges):
+            if also is not None and k == 0:
+                L.check(lib.mg_fused_also_rows(also[0], also[1], *(crows(*also) if mode in ("finest", "descent_no_x") else (0, 0))))
+            cs = (dc.data_ptr(), ny, nx, ld, cny, cnx, dc.stride(0))
+            if mode == "finest":
+                L.check(lib.mg_smooth_fused_restrict(db.data_ptr(), dx.data_ptr(), out.data_ptr(), rr.data_ptr(), *cs, j0, j1, flo, fhi,
+                                                     oj, 6, h, 1.0, slots.data_ptr(), 0, cb.data_ptr(), cny, cnx, cb.stride(0),
+                                                     *crows(j0, j1), 1, 0, 0, 0, st))
+            elif mode == "descent_no_x":
+                L.check(lib.mg_smooth_fused_restrict(db.data_ptr(), None, None, None, None, ny, nx, ld, 0, 0, 0, j0, j1, flo, fhi,
+                                                     oj, 3, h, 1.0, slots.data_ptr(), 0, cb.data_ptr(), cny, cnx, cb.stride(0),
+                                                     *crows(j0, j1), 1, 0, 0, 0, st))
+            elif mode == "ascent":
+                L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), out.data_ptr(), None, *cs, j0, j1, flo, fhi, oj, 6, 0, h,
+                                            1.0, None, 1, 0, 0, st))
+            else:
+                L.check(lib.mg_smooth_fused(db.data_ptr(), None, out.data_ptr(), None, *cs, j0, j1, flo, fhi, oj, 9, 3, h, 1.0,
+                                            None, 1, 0, 0, st))
+        nrm = C.c_double()
+        L.check(lib.mg_norm_read(slots.data_ptr(), C.byref(nrm), st))
+        return out.cpu().numpy(), rr.cpu().numpy(), cb.cpu().numpy(), nrm.value
+
+    try:
+        two = run([(2, a), (e, ny - 1)], None)
+        one = run([(2, a)], (e, ny - 1))
+        for got, want in zip(one, two):
+            assert np.array_equal(got, want)
+        if mode != "descent_no_x":
+            assert np.all(two[0][a:e] == 7.0) and not np.all(two[0][e : ny - 1] == 7.0)
+        # consumed: the next call covers its own range only
+        first_only = run([(2, a)], None)
+        L.check(lib.mg_fused_also_rows(e, ny - 1, 0, 0))
+        L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), padded(x).data_ptr(), None, None, ny, nx, ld, 0, 0, 0, 2, 3, flo,
+                                    fhi, oj, 1, 0, h, 1.0, None, 1, 0, 0, st))
+        again = run([(2, a)], None)
+        for got, want in zip(again, first_only):
+            assert np.array_equal(got, want)
+        # only the second range has rows
+        empty_first = run([(2, 2)], (e, ny - 1))
+        second_only = run([(e, ny - 1)], None)
+        for got, want in zip(empty_first, second_only):
+            assert np.array_equal(got, want)
+        # rejected: a second range that does not follow the first; the failed call consumes the setting too
+        L.check(lib.mg_fused_also_rows(2, a, 0, 0))
+        o = padded(x)
+        assert lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), o.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, e, ny - 1, flo, fhi,
+                                   oj, 3, 0, h, 1.0, None, 1, 0, 0, st) != 0
+        assert b"second row range" in lib.mg_last_error()
+        L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), o.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, e, ny - 1, flo, fhi,
+                                    oj, 3, 0, h, 1.0, None, 1, 0, 0, st))
+        assert lib.mg_fused_also_rows(5, 4, 0, 0) != 0
+    finally:
+        L.check(lib.mg_set_fused_tuning(2, 0))

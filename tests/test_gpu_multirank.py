@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, gny, gnx, n_para, h, b, cycles, fused, dist_min_rows, kw, q):
+    from tests.mp_util import rank_watchdog
+    rank_watchdog(int(os.environ.get("MG_TEST_RANK_WATCHDOG", "150")))
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

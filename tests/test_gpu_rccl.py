@@ -92,6 +92,24 @@ def _worker(port, q):
             runs.append((errs, eng.local_rows(eng.x0).cpu().numpy()))
             eng.close()
         graphs_ok = runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+        # a capture that begins right after a collective on the same stream and stays open while torch's watchdog
+        # thread polls that collective's end event (every 100 ms): the multi-GPU engine captures the replicated
+        # middle of the cycle right after the all-gather.  HipOps records on a stream of its own for this reason;
+        # on the collective's stream the poll fails with hipErrorCapturedEvent and ends the process.
+        for _ in range(3):
+            ops.begin()
+            for _ in range(20):
+                ops.zero_(scratch)
+            comm.allgather_rows(out[2:2 + rows], inp)
+            ops.graph_begin()
+            ops.zero_(scratch)
+            time.sleep(0.35)
+            ops.zero_(scratch)
+            g = ops.graph_end()
+            ops.graph_launch(g)
+            ops.stream.synchronize()
+            ops.graph_destroy(g)
+            ops.end()
         ok = (bool(torch.equal(x, want)) and bool(scratch.eq(0).all()), bool(torch.equal(out[2:2 + rows], inp)), bool(out[:2].eq(0).all() and out[2 + rows:].eq(0).all()),
               bool(torch.equal(slots, before)), graphs_ok)
         q.put((ok, per_round))
