@@ -271,6 +271,15 @@ int mg_split(const double *a_in, int64_t in_ny, int64_t in_nx, int64_t in_ld, do
  * of the V-cycle, or the whole cycle on one GPU).  mg_graph_end returns an executable graph.
  */
 int mg_graph_begin(void *stream);
+/*
+ * The same on a stream the library makes for this one capture and returns: enqueue on *stream_out what is to be
+ * recorded, then pass it to mg_graph_end, which releases it.  For processes that also hold an RCCL communicator
+ * through torch.distributed: its watchdog thread polls the end events of outstanding collectives, and on this HIP
+ * runtime that poll fails (hipErrorCapturedEvent; torch then ends the process) while a stream that has waited for
+ * such an event is capturing.  A stream that has never carried anything is safe.  (No counterpart in the reference,
+ * whose ranks launch nothing asynchronously.)
+ */
+int mg_graph_begin_own(void **stream_out);
 int mg_graph_end(void *stream, void **graph_exec_out);
 int mg_graph_launch(void *graph_exec, void *stream);
 int mg_graph_destroy(void *graph_exec);

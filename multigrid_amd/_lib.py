@@ -55,6 +55,7 @@ SIGNATURES = {
     "mg_zero": ([_p, _i, _p], _n),
     "mg_split": ([_p, _i, _i, _i, _p, _i, _i, _i, _p], _n),
     "mg_graph_begin": ([_p], _n),
+    "mg_graph_begin_own": ([C.POINTER(_p)], _n),
     "mg_graph_end": ([_p, C.POINTER(_p)], _n),
     "mg_graph_launch": ([_p, _p], _n),
     "mg_graph_destroy": ([_p], _n),

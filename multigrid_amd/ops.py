@@ -29,7 +29,7 @@ class HipOps:
         self._side, self._on_side, self._side_pending = None, False, False
         self._copy = None
         self._comm, self._on_comm, self._comm_done = None, False, None
-        self._cap, self._cap_swap = None, None
+        self._cap_swap = None  # (attribute, stream) that a graph capture's own stream stands in for
 
     # ---- memory / stream plumbing (torch) -------------------------------------------------
     def zeros(self, rows, ld, batch=None):
@@ -261,38 +261,30 @@ class HipOps:
 
     def graph_begin(self):
         """Start recording the calls that follow into a graph instead of running them.  They are recorded on a
-        stream of their own that stands in for the current one (main or side) until graph_end(): in a process
-        that holds an RCCL communicator, torch's watchdog thread polls the end events of outstanding collectives,
-        and on this HIP runtime such a poll fails with hipErrorCapturedEvent -- and takes the process down --
-        while a stream that has waited for one of those events is capturing (tools/rccl_capture_probe.py).  A
-        stream that never waits for anything but this object's own events is safe; a graph can be launched on
-        any stream."""
-        if self._cap is None:
-            self._cap = torch.cuda.Stream(self.device)
+        stream the library makes for this one capture (mg_graph_begin_own), which stands in for the current one
+        (main or side) until graph_end(): in a process that holds an RCCL communicator, torch's watchdog thread
+        polls the end events of outstanding collectives, and on this HIP runtime such a poll fails with
+        hipErrorCapturedEvent -- and takes the process down -- while a stream that has waited for one of those
+        events is capturing (tools/rccl_capture_probe.py).  A graph can be launched on any stream."""
         assert self._cap_swap is None, "graph captures do not nest"
+        raw = C.c_void_p()
+        check(self.L.mg_graph_begin_own(C.byref(raw)))
+        cap = torch.cuda.ExternalStream(raw.value, device=self.device)
         if self._on_side:
             self._cap_swap = ("_side", self._side)
-            self._side = self._cap
+            self._side = cap
         else:
             self._cap_swap = ("stream", self.stream)
-            self.stream = self._cap
-        try:
-            check(self.L.mg_graph_begin(self._s))
-        except Exception:
-            self._graph_restore()
-            raise
-
-    def _graph_restore(self):
-        name, stream = self._cap_swap
-        setattr(self, name, stream)
-        self._cap_swap = None
+            self.stream = cap
 
     def graph_end(self):
         g = C.c_void_p()
         try:
-            check(self.L.mg_graph_end(self._s, C.byref(g)))
+            check(self.L.mg_graph_end(self._s, C.byref(g)))  # releases the capture's stream as well
         finally:
-            self._graph_restore()
+            name, stream = self._cap_swap
+            setattr(self, name, stream)
+            self._cap_swap = None
         return g
 
     def graph_launch(self, g):
