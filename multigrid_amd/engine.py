@@ -49,7 +49,8 @@ class SlabMultigrid:
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
                  store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
                  recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=False,
-                 overlap_min_rows=4096, batch_stop="max", fine_smoother="jacobi", comm=None):
+                 overlap_min_rows=4096, batch_stop="max", fine_smoother="jacobi", comm=None,
+                 recompute_last_distributed=True):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -117,6 +118,7 @@ class SlabMultigrid:
         # need not store x at all.  16 B per point less traffic on every coarse level, identical values.
         self.recompute_presmoothing = recompute_presmoothing
         self.recompute_min_nx, self.recompute_min_blocks = recompute_min_nx, recompute_min_blocks
+        self.recompute_last_distributed = recompute_last_distributed
         # With the reference's loop bounds nothing computed on the whole-domain levels below the first
         # ever reaches the solution (:302).  They are a pure function of rw[0], so unless asked to they
         # are not computed every cycle but on demand (sync_whole_levels), with identical values.
@@ -693,6 +695,12 @@ class SlabMultigrid:
             return False
         if self.world > 1 and l < self.n_dist and self.plan.halo < self.N1 + self.N2 + 1:
             return False  # a slab needs a halo as deep as both smoothings together
+        if self.world > 1 and l + 1 == self.n_dist and self.recompute_last_distributed:
+            # The last distributed level, whatever its size: its correction is a window of the replicated level below,
+            # halo included, so in this scheme nothing is exchanged in front of its ascent pass -- one round less on
+            # the cycle's critical path (a level this small cannot hide a round behind its interior rows), which
+            # outweighs what the deeper pipeline costs on a narrow level.
+            return True
         # The 9-deep pass pays with wider overlaps (20 of 128 columns, 18 rows per tile end), which a
         # level must be wide enough and have workgroups enough to absorb (measured: it wins from
         # 8193 x 8193 on, loses at 4097 x 4097 and on batches of narrow grids).
