@@ -110,6 +110,33 @@ def _worker(port, q):
             ops.stream.synchronize()
             ops.graph_destroy(g)
             ops.end()
+        # The whole multi-rank engine over these RCCL calls, the rank being its own neighbours (values are meaningless
+        # then; that every call is accepted, the counts, and that nothing ends the process are not): cut passes on
+        # the communication stream, both slab ends in one launch, the all-gather, the replicated middle and the dead
+        # levels captured into graphs right after RCCL traffic, solve()'s order of norm reads, close().
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        from loopback_comm import LoopbackComm
+        engine_runs = []
+        for world, rank in ((2, 0), (4, 2), (8, 7)):
+            gny, gnx = world * 1024 + 1, 1025
+            ops2 = HipOps(torch.device("cuda", 0))
+            lc = LoopbackComm(ops2, world, rank, rccl=True)
+            eng = SlabMultigrid(gny, gnx, 6, 0.01, 0.0, ops=ops2, world=world, rank=rank, comm=lc, eager_dead_levels=True,
+                                overlap_min_rows=1, dist_min_rows=64, max_cycles=3)
+            a, e = eng.owned_rows()
+            eng.set_b_rows(torch.from_numpy(rng.standard_normal((e - a, gnx))).cuda())
+            eng.presmooth()
+            r0 = lc.rounds
+            errs = eng.cycles(3)
+            per_cycle = (lc.rounds - r0) / 3
+            eng.solve()
+            # (solve() may stop before its third cycle: with the rank's own rows as halo the divergence latch can trip)
+            engine_runs.append((len(errs), bool(np.isfinite(errs).all()), per_cycle, eng.rounds_per_cycle(), eng.split_passes > 0,
+                                1 <= eng.it <= 3, eng.n_dist >= 2))
+            eng.close()
+        print("loopback engine runs:", engine_runs, flush=True)
+        graphs_ok = graphs_ok and all(r[0] == 3 and r[1] and r[2] == r[3] and r[4] and r[5] and r[6] for r in engine_runs)
         ok = (bool(torch.equal(x, want)) and bool(scratch.eq(0).all()), bool(torch.equal(out[2:2 + rows], inp)), bool(out[:2].eq(0).all() and out[2 + rows:].eq(0).all()),
               bool(torch.equal(slots, before)), graphs_ok)
         q.put((ok, per_round))

@@ -30,6 +30,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
@@ -54,7 +55,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from multigrid_amd.comm import SlabComm
+    from loopback_comm import LoopbackComm
     from multigrid_amd.engine import SlabMultigrid
     from multigrid_amd.levels import choose_n_para
     from multigrid_amd.ops import HipOps
@@ -71,71 +72,13 @@ def main():
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True) if args.rccl_high_priority else None
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), pg_options=opts)
 
-    class LoopbackComm(SlabComm):
-        """SlabComm of rank `rank` of `world`, every peer being this process."""
-
-        def __init__(self, ops):
-            self.ops, self.group, self.world, self.rank = ops, None, world, rank
-            self.staged, self.rounds = False, 0
-            self.rccl = args.comm == "rccl"
-            if self.rccl:
-                t = ops.zeros(1, 1)
-                self.allreduce_max(t.view(-1))
-
-        def _peer(self, r):
-            return 0
-
-        def prepare(self, sends, recvs):
-            # what I send up is shaped like what comes from below, and the other way round
-            assert sorted(t.numel() for t, _ in sends) == sorted(t.numel() for t, _ in recvs) or world == 1 or \
-                rank in (0, world - 1)
-            if self.rccl:
-                n = min(len(sends), len(recvs))  # an end rank has one neighbour: equally many each way
-                return SlabComm.prepare(self, sends[:n], recvs[:n])
-            pairs = []
-            rs = list(recvs)
-            for t, _ in sends:
-                k = next((i for i, (u, _) in enumerate(rs) if u.numel() == t.numel()), None)
-                if k is not None:
-                    pairs.append((rs.pop(k)[0], t))
-            return ("copy", pairs)
-
-        def run(self, batch):
-            if batch[0] != "copy":
-                return SlabComm.run(self, batch)
-            if not batch[1]:
-                return
-            self.rounds += 1
-            with self.ops.ctx():
-                for dst, src in batch[1]:
-                    dst.copy_(src)
-
-        def allgather_rows(self, out, inp):
-            self.rounds += 1
-            R = inp.shape[0]
-            own = out[rank * R : (rank + 1) * R]
-            with self.ops.ctx():
-                if self.rccl:
-                    dist.all_gather_into_tensor(own.view(-1), inp.view(-1))
-                else:
-                    own.copy_(inp)
-                for q in range(world):  # the other ranks' rows: written once more on this device
-                    if q != rank:
-                        out[q * R : (q + 1) * R].copy_(own)
-
-        def allreduce_max(self, t):
-            if self.rccl:
-                with self.ops.ctx():
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return t
-
     n = args.n
     gnx = 2 ** (n + 1) + 1
     gny = world * 2 ** (n + 1) + 1
     n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=max(1, n - 4))
     h = 20.0 / 2 ** (n + 1)
     ops = HipOps()
-    comm = LoopbackComm(ops) if world > 1 else None
+    comm = LoopbackComm(ops, world, rank, rccl=args.comm == "rccl") if world > 1 else None
     extra = json.loads(args.engine_args)
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, ops=ops, world=world, rank=rank, comm=comm, eager_dead_levels=True,
                         tune_placement=not args.no_tune_placement, overlap_min_rows=args.overlap_min_rows,
