@@ -253,7 +253,7 @@ extern "C" int mg_set_tuning(const char *key, int value)
         MG_REQUIRE(value == 1 || value == 2 || value == 4, "mg_set_tuning: fused_waves must be 1, 2 or 4");
         g_fused_waves = value;
     } else if (!strcmp(key, "fused_min_rows")) {
-        MG_REQUIRE(value >= 4 && value <= 128, "mg_set_tuning: fused_min_rows must be 4..128");
+        MG_REQUIRE(value >= 1 && value <= 128, "mg_set_tuning: fused_min_rows must be 1..128");
         g_fused_min_rows = value;
     } else if (!strcmp(key, "fused_min_blocks")) {
         MG_REQUIRE(value >= 1 && value <= (1 << 20), "mg_set_tuning: fused_min_blocks must be 1..2^20");

@@ -705,7 +705,8 @@ def test_fused_pass_equals_oracle_kernels(L, shape, mode):
 # never a value: (key, value, key's default)
 KNOBS = [("stream_min_mib", 0, 256), ("fused_lockstep", 0, 1), ("fused_lockstep", 3, 1), ("fused_rows", 7, 0), ("fused_rows", 24, 0),
          ("fused_rows", 256, 0), ("fused_rows_shallow", 64, 32), ("fused_rows_deep", 32, 128), ("fused_waves", 1, 4),
-         ("fused_waves", 2, 4), ("xcd_stagger", -1, 0), ("xcd_stagger", 3, 0), ("fused_min_rows", 4, 8), ("fused_min_blocks", 1, 2048)]
+         ("fused_waves", 2, 4), ("xcd_stagger", -1, 0), ("xcd_stagger", 3, 0), ("fused_min_rows", 4, 8), ("fused_min_rows", 2, 8), ("fused_min_rows", 1, 8),
+         ("fused_min_blocks", 1, 2048)]
 
 
 @pytest.mark.parametrize("knob", KNOBS, ids=lambda k: f"{k[0]}={k[1]}")
