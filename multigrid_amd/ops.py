@@ -184,19 +184,20 @@ class HipOps:
         omega < 1: damped sweeps, x + omega * (t - x).  also_rows = (j2, j3, T2, T3): the same launch
         also produces rows j2 .. j3-1 (and restricts into coarse rows T2 .. T3-1)."""
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        if also_rows is not None:
-            check(self.L.mg_fused_also_rows(*also_rows))
         self._same_layout(b, x_in, x_out, r)
         nb, bs, ny, ld = self._nb(b)
         _, cs, cny, cld = self._nb(crs) if crs is not None else (1, 0, 0, 0)
         common = (p(b), p(x_in), p(x_out), p(r), p(crs), ny, nx, ld, cny, cnx, cld, j0, j1, fix_lo, fix_hi, oj, sweeps)
-        if coarse_b is None:
-            check(self.L.mg_smooth_fused(*common, prolong_after, h, omega, p(norm), nb, bs, cs, self._s))
-        else:
+        if coarse_b is not None:
             _, cbs, cbny, cbld = self._nb(coarse_b)
             assert prolong_after == 0
             # a (batch, slots) accumulator: every problem of the batch has its own max-norm
             nstride = norm.stride(0) if (norm is not None and norm.dim() == 2) else 0
+        if also_rows is not None:  # consumed by the call that follows, whatever it returns
+            check(self.L.mg_fused_also_rows(*also_rows))
+        if coarse_b is None:
+            check(self.L.mg_smooth_fused(*common, prolong_after, h, omega, p(norm), nb, bs, cs, self._s))
+        else:
             check(self.L.mg_smooth_fused_restrict(*common, h, omega, p(norm), nstride, p(coarse_b), cbny, cbnx, cbld, T0, T1, nb,
                                                   bs, cs, cbs, self._s))
 
