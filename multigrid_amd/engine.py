@@ -538,12 +538,14 @@ class SlabMultigrid:
         launch(a, e)                    # enqueued first: the GPU has work while the host sets the exchange up
         with self.ops.comm_side(ready):
             self._exchange(items)
+            # the slab ends follow the exchange on ITS stream: they run beside the interior rows (which write other
+            # rows of the same arrays) instead of after them
+            if getattr(self.ops, "supports_also_rows", False):
+                launch(L.t0, a, (e, L.t1))  # both ends in one launch
+            else:
+                launch(L.t0, a)
+                launch(e, L.t1)
         self.ops.comm_join()
-        if getattr(self.ops, "supports_also_rows", False):
-            launch(L.t0, a, (e, L.t1))  # both slab ends in one launch
-        else:
-            launch(L.t0, a)
-            launch(e, L.t1)
 
     @staticmethod
     def _cut(L, D):

@@ -42,7 +42,9 @@ class HipOps:
 
     @property
     def _s(self):
-        return (self._side if self._on_side else self.stream).cuda_stream
+        """The stream kernels are enqueued on: the communication stream inside comm_side(), the side stream inside
+        side(), else the main one."""
+        return (self._comm if self._on_comm else self._side if self._on_side else self.stream).cuda_stream
 
     # Work that nothing later in the cycle reads can run beside the main sequence: side() routes the
     # calls made inside it to a second stream that starts after everything enqueued so far, and
@@ -79,7 +81,9 @@ class HipOps:
     # An exchange whose result is not needed at once can run beside the kernels that follow it: inside
     # comm_side() the context torch.distributed calls are issued in (ctx()) is a communication stream
     # that starts at a mark() of the main sequence (default: after everything enqueued so far); the
-    # main sequence goes on without waiting until comm_join().
+    # main sequence goes on without waiting until comm_join().  Kernels launched inside comm_side() go to
+    # that stream too, behind the exchange: the rows of a pass that need the halo run there, beside the
+    # interior rows on the main stream.
     @contextlib.contextmanager
     def comm_side(self, after=None):
         if self._comm is None:
