@@ -58,7 +58,9 @@ const char *mg_last_error(void);
  *                            them from displacing in L2 / the Infinity Cache the rows other tiles re-read (default 256;
  *                            a value beyond every array size switches them off)
  *   "sor_single_wave" 0|1|2  mg_sor, lexicographic: barrier-free one-wave kernel never / where it is
- *                            faster (default) / wherever the grid fits */
+ *                            faster (default) / wherever the grid fits
+ *   "sor_transpose"   0|1    mg_sor, lexicographic: a grid with more rows than columns is walked along its columns
+ *                            by the one-wave kernel when that needs fewer rows per lane (default 1; same values) */
 int mg_set_tuning(const char *key, int value);
 
 /*

@@ -165,15 +165,21 @@ __global__ __launch_bounds__(1024) void mg_sor_wavefront_kernel(const double *__
 #define SORW_GUARD 32      // doubles in front of the grid in LDS: >= 3 * SORW_PF + 8 (see sor_wave_sweep)
 #define SORW_GUARD_BACK 96 // behind it: the same, plus one dummy slot per lane for the writes of inactive cells
 
-template <int RPL, int DIR>
-__device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, double *sx, double *dummy, int ny, int nx,
-                                               int ld, int ldl, double h2, int lane)
+// TR: the wave walks the TRANSPOSED grid (ny, nx here are the transposed grid's rows and columns; sx holds x
+// transposed, sb the right-hand side transposed, with guard zones like sx's).  A grid with many rows and few columns
+// then needs fewer rows per lane.  The lexicographic sweep visits a cell after its upper and left neighbours and
+// before its lower and right ones whichever of the two directions is the inner one, so the transposed wavefront
+// applies the same updates; the sum keeps the reference's operand order, (E + W) + S + N of the original grid.
+template <int RPL, int DIR, bool TR>
+__device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, double *sx, const double *sb, double *dummy, int ny,
+                                               int nx, int ld, int ldl, double h2, int lane)
 {
     constexpr int PF = SORW_PF;
     const double a = 1.5, alpha = 1 - a, beta = a / 4;
     int j[RPL]; // row of slot k, clamped to the bottom boundary row: lanes beyond it stream that row again (unused)
     bool inter[RPL];
     double *srow[RPL];
+    const double *sbrow[RPL];
     int boff[RPL];
     double self[RPL], lat[RPL];
     const int d0 = DIR > 0 ? 0 : ny + nx - 1;               // first step: row 1 at column -1 / row ny-1 at column nx
@@ -188,6 +194,7 @@ __device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, doubl
         // grid of at least 3 columns, and the highest is row ny-1 at column nx + 3*PF, inside the back guard.
         j[k] = jr < ny - 1 ? jr : ny - 1;
         srow[k] = sx + j[k] * ldl;
+        sbrow[k] = TR ? sb + j[k] * ldl : nullptr;
         boff[k] = j[k] * ld;
         self[k] = 0, lat[k] = 0;
     }
@@ -203,11 +210,15 @@ __device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, doubl
             // forward: ahead = X(j, c+1), c = cb+u;  backward: ahead = X(j, c-1), c = cb-u  (offsets kept >= 0)
             const double *pa = DIR > 0 ? srow[k] + cb + 1 : srow[k] + cb - 1 - (PF - 1);
             const int ob = (boff[k] + (DIR > 0 ? cb : cb - (PF - 1))) * 8;
+            const double *pbv = TR ? (DIR > 0 ? sbrow[k] + cb : sbrow[k] + cb - (PF - 1)) : nullptr;
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int w = DIR > 0 ? u : PF - 1 - u;
                 q.ah[k][u] = pa[w];
-                q.bv[k][u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(brs, ob + w * 8, 0, 0));
+                if constexpr (TR)
+                    q.bv[k][u] = pbv[w];
+                else
+                    q.bv[k][u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(brs, ob + w * 8, 0, 0));
             }
         }
         const int c0 = dd - 1; // column of row 1: the top boundary row is read there (used by lane 0 only)
@@ -255,7 +266,10 @@ __device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, doubl
                 const double ahead = q.ah[k][u];
                 const double E = DIR > 0 ? ahead : lat[k];
                 const double W = DIR > 0 ? lat[k] : ahead;
-                double v = alpha * self[k] + beta * (E + W + below[k] + above[k] - h2 * q.bv[k][u]);
+                // transposed: this grid's lower/upper neighbours are the original's east/west, its east/west the
+                // original's lower/upper
+                double v = TR ? alpha * self[k] + beta * (below[k] + above[k] + E + W - h2 * q.bv[k][u])
+                              : alpha * self[k] + beta * (E + W + below[k] + above[k] - h2 * q.bv[k][u]);
                 v = act ? v : self[k];
                 double *dst = act ? pw[k] : dummy;
                 dst[w] = v;
@@ -274,40 +288,55 @@ __device__ __forceinline__ void sor_wave_sweep(__amdgpu_buffer_rsrc_t brs, doubl
     }
 }
 
-template <int RPL>
+template <int RPL, bool TR = false>
 __global__ __launch_bounds__(256) void mg_sor_wave_kernel(const double *__restrict__ b, double *x,
                                                           double *__restrict__ r, int ny, int nx, int ld, int ldl,
                                                           double h2, int iterations, int backward, i64 bstride)
 {
     extern __shared__ double smem[];
+    // the grid the wave walks: the array's, or its transpose (ldl is that grid's row pitch in LDS)
+    const int wy = TR ? nx : ny, wx = TR ? ny : nx;
     double *const sx = smem + SORW_GUARD;           // the grid; guard zones on both sides
-    double *const dummy = sx + ny * ldl + (threadIdx.x & 63); // inactive cells write here (inside the back guard)
+    double *const sb = TR ? sx + wy * ldl + SORW_GUARD_BACK + SORW_GUARD : nullptr; // transposed: b as well, laid out alike
+    double *const dummy = sx + wy * ldl + (threadIdx.x & 63); // inactive cells write here (inside the back guard)
     b += (i64)blockIdx.x * bstride;
     x += (i64)blockIdx.x * bstride;
     if (r) r += (i64)blockIdx.x * bstride;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // element (j, i) of the array in LDS
+    auto at = [&](int j, int i) -> double & { return TR ? sx[i * ldl + j] : sx[j * ldl + i]; };
     for (int j = wv; j < ny; j += 4)
-        for (int i = lane; i < nx; i += 64) sx[j * ldl + i] = x[(i64)j * ld + i];
+        for (int i = lane; i < nx; i += 64) {
+            at(j, i) = x[(i64)j * ld + i];
+            if constexpr (TR) sb[i * ldl + j] = b[(i64)j * ld + i];
+        }
     if (tid < SORW_GUARD) smem[tid] = 0.0;
-    if (tid < SORW_GUARD_BACK) sx[ny * ldl + tid] = 0.0;
+    if (tid < SORW_GUARD_BACK) sx[wy * ldl + tid] = 0.0;
+    if constexpr (TR) {
+        if (tid < SORW_GUARD) sb[tid - SORW_GUARD] = 0.0;
+        if (tid < SORW_GUARD_BACK) sb[wy * ldl + tid] = 0.0;
+        // the pad column of every row (the pitch is even, the row length may be odd) is read as a cell's neighbour
+        // in the streaming loop like any other: defined values, never used
+        if (ldl > wx)
+            for (int q = tid; q < wy; q += 256) sb[q * ldl + wx] = 0.0, sx[q * ldl + wx] = 0.0;
+    }
     __syncthreads();
     if (wv == 0) {
-        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)b, 0, ny * ld * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)b, 0, TR ? 0 : ny * ld * 8, 0x00020000);
         for (int it = 0; it < iterations; ++it) {
-            sor_wave_sweep<RPL, 1>(brs, sx, dummy, ny, nx, ld, ldl, h2, lane);
-            if (backward) sor_wave_sweep<RPL, -1>(brs, sx, dummy, ny, nx, ld, ldl, h2, lane);
+            sor_wave_sweep<RPL, 1, TR>(brs, sx, sb, dummy, wy, wx, ld, ldl, h2, lane);
+            if (backward) sor_wave_sweep<RPL, -1, TR>(brs, sx, sb, dummy, wy, wx, ld, ldl, h2, lane);
         }
     }
     __syncthreads();
     const double hh = 1 / h2;
     for (int j = wv; j < ny; j += 4)
         for (int i = lane; i < nx; i += 64) {
-            const double c = sx[j * ldl + i];
+            const double c = at(j, i);
             x[(i64)j * ld + i] = c;
             if (r && j >= 1 && j <= ny - 2 && i >= 1 && i <= nx - 2) {
-                const double left = sx[j * ldl + i - 1] * hh, cent = c * hh;
-                r[(i64)j * ld + i] = b[(i64)j * ld + i] - left -
-                                     (sx[j * ldl + i + 1] + sx[(j - 1) * ldl + i] + sx[(j + 1) * ldl + i]) * hh + cent * 4;
+                const double left = at(j, i - 1) * hh, cent = c * hh;
+                r[(i64)j * ld + i] = b[(i64)j * ld + i] - left - (at(j, i + 1) + at(j - 1, i) + at(j + 1, i)) * hh + cent * 4;
             }
         }
 }
@@ -356,7 +385,7 @@ extern "C" int mg_gauss_seidel_rb(const double *b, double *x, i64 ny, i64 nx, i6
 // The LDS limit of a kernel is an attribute of the function PER DEVICE: it is set once on every device a launch is
 // made on (flags per device and kernel group; setting it twice from two host threads is harmless).
 #define SOR_MAX_DEVICES 64
-static std::atomic<unsigned char> g_lds_attr[SOR_MAX_DEVICES][2];
+static std::atomic<unsigned char> g_lds_attr[SOR_MAX_DEVICES][3];
 static bool lds_attr_done(int which)
 {
     int d = 0;
@@ -369,6 +398,7 @@ static void lds_attr_mark(int which)
     if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < SOR_MAX_DEVICES) g_lds_attr[d][which].store(1, std::memory_order_release);
 }
 
+int g_sor_transpose = 1;   // tuning knob "sor_transpose": walk tall narrow grids transposed (0 = never)
 int g_sor_single_wave = 1; // tuning knob "sor_single_wave": 0 = never, 1 = where it is faster, 2 = wherever it fits
 
 extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64 ld, double h, i64 iterations,
@@ -389,6 +419,29 @@ extern "C" int mg_sor(const double *b, double *x, double *r, i64 ny, i64 nx, i64
         const bool lds = ny * (i64)ldl <= MG_SOR_LDS_DOUBLES;
         int nt = (int)(((ny - 2) + 63) / 64 * 64);
         if (nt > 1024) nt = 1024;
+        // A grid with more rows than columns whose transpose needs fewer rows per lane is walked transposed
+        // (129 x 17: one row per lane instead of two, 64 instead of 109 us for three sweeps both ways).
+        const int ldt = (int)((ny + 1) & ~(i64)1);
+        const i64 t_doubles = 2 * (nx * (i64)ldt + SORW_GUARD + SORW_GUARD_BACK);
+        if (g_sor_single_wave >= 1 && g_sor_transpose && nx < ny && nx - 1 <= 128 && (nx - 1 + 63) / 64 < (ny - 1 + 63) / 64 &&
+            t_doubles <= MG_SOR_LDS_DOUBLES + SORW_GUARD + SORW_GUARD_BACK) {
+            if (!lds_attr_done(2)) {
+                const int cap = (MG_SOR_LDS_DOUBLES + SORW_GUARD + SORW_GUARD_BACK) * (int)sizeof(double);
+                MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                MG_HIP(hipFuncSetAttribute((const void *)mg_sor_wave_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                lds_attr_mark(2);
+            }
+            const dim3 grid((unsigned)nbatch), block(256);
+            const size_t bytes = (size_t)t_doubles * sizeof(double);
+            if (nx - 1 <= 64)
+                hipLaunchKernelGGL((mg_sor_wave_kernel<1, true>), grid, block, bytes, st, b, x, r, (int)ny, (int)nx, (int)ld, ldt, h2,
+                                   (int)iterations, backward, bstride);
+            else
+                hipLaunchKernelGGL((mg_sor_wave_kernel<2, true>), grid, block, bytes, st, b, x, r, (int)ny, (int)nx, (int)ld, ldt, h2,
+                                   (int)iterations, backward, bstride);
+            MG_LAUNCH_CHECK("mg_sor (single-wave wavefront, transposed)");
+            return 0;
+        }
         // measured 1.6-2.6x ahead of the one-thread-per-row kernel with one or two rows per lane
         if (lds && ny - 1 <= 64 * 4 && ny * ld < ((i64)1 << 27) && (g_sor_single_wave == 2 || (g_sor_single_wave == 1 && ny - 1 <= 128))) {
             const size_t bytes = ((size_t)ny * ldl + SORW_GUARD + SORW_GUARD_BACK) * sizeof(double);

@@ -227,6 +227,7 @@ static int g_rows = 0;      // rows per tile, 0 = automatic
 static int g_linear_map = 0;
 i64 g_stream_min_bytes = (i64)256 << 20; // the Infinity Cache's size: what is larger cannot stay cached anyway
 extern int g_sor_single_wave; // mg_sor.hip
+extern int g_sor_transpose;   // mg_sor.hip
 extern int g_fused_waves;     // mg_fused.hip
 extern int g_fused_min_rows;  // mg_fused.hip
 extern int g_fused_min_blocks; // mg_fused.hip
@@ -273,6 +274,9 @@ extern "C" int mg_set_tuning(const char *key, int value)
     } else if (!strcmp(key, "stream_min_mib")) {
         MG_REQUIRE(value >= 0, "mg_set_tuning: stream_min_mib must be >= 0");
         g_stream_min_bytes = (i64)value << 20;
+    } else if (!strcmp(key, "sor_transpose")) {
+        MG_REQUIRE(value == 0 || value == 1, "mg_set_tuning: sor_transpose must be 0 or 1");
+        g_sor_transpose = value;
     } else if (!strcmp(key, "sor_single_wave")) {
         MG_REQUIRE(value >= 0 && value <= 2, "mg_set_tuning: sor_single_wave must be 0, 1 or 2");
         g_sor_single_wave = value;

@@ -266,18 +266,22 @@ def test_transfer_whole_domain(mm, fshape, cshape):
 
 
 SOR_SHAPES = [(3, 3), (5, 5), (4, 7), (9, 9), (33, 33), (65, 257), (129, 129), (141, 139), (1100, 9), (257, 257), (1030, 40),
-              (65, 65), (66, 40), (64, 200), (5, 1000), (128, 128), (130, 90), (200, 90), (257, 65), (258, 20), (17, 3), (3, 17)]
+              (65, 65), (66, 40), (64, 200), (5, 1000), (128, 128), (130, 90), (200, 90), (257, 65), (258, 20), (17, 3), (3, 17),
+              (129, 17), (129, 33), (65, 9), (131, 4), (1025, 9)]
 
 
 @pytest.mark.parametrize("shape", SOR_SHAPES, ids=str)
 @pytest.mark.parametrize("its", [1, 3])
-@pytest.mark.parametrize("single_wave", [2, 0])
-def test_sor_lexicographic_vs_oracle(mm, L, shape, its, single_wave):
-    """Wavefront execution (one wave with lane shifts, one thread per row in LDS, global memory) ==
-    row-major Gauss-Seidel, bit for bit."""
+@pytest.mark.parametrize("single_wave,transpose", [(2, 1), (2, 0), (0, 1)])
+def test_sor_lexicographic_vs_oracle(mm, L, shape, its, single_wave, transpose):
+    """Wavefront execution (one wave with lane shifts -- along the rows, or along the columns of a grid that has
+    more rows than columns --, one thread per row in LDS, global memory) == row-major Gauss-Seidel, bit for bit."""
+    if transpose == 0 and shape[0] <= shape[1]:
+        pytest.skip("only grids with more rows than columns are walked transposed")
     rng = np.random.default_rng(shape[0] * 7 + its)
     b, x0, r0 = rng.standard_normal(shape), rng.standard_normal(shape), rng.standard_normal(shape)
     L.check(L.lib().mg_set_tuning(b"sor_single_wave", single_wave))
+    L.check(L.lib().mg_set_tuning(b"sor_transpose", transpose))
     try:
         for fn in ("smooth", "smooth_altern"):
             x_ref, r_ref = x0.copy(), r0.copy()
@@ -288,6 +292,7 @@ def test_sor_lexicographic_vs_oracle(mm, L, shape, its, single_wave):
             assert np.array_equal(dr.cpu().numpy(), r_ref), fn
     finally:
         L.check(L.lib().mg_set_tuning(b"sor_single_wave", 1))
+        L.check(L.lib().mg_set_tuning(b"sor_transpose", 1))
 
 
 @pytest.mark.parametrize("shape", [(3, 3), (9, 9), (33, 65), (129, 129), (513, 513)], ids=str)
