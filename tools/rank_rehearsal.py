@@ -48,6 +48,7 @@ def main():
                     help="read every cycle's norm before the next cycle is issued, as solve() must")
     ap.add_argument("--overlap-min-rows", type=int, default=4096)
     ap.add_argument("--dist-min-rows", type=int, default=None)
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the (2**(n+1)+1)^2 grid cut into N slabs (bench.py --strong)")
     ap.add_argument("--rccl-high-priority", action="store_true", help="RCCL's own streams at high priority")
     ap.add_argument("--engine-args", default="{}", help="JSON dict of further SlabMultigrid keyword arguments")
     args = ap.parse_args()
@@ -74,7 +75,7 @@ def main():
 
     n = args.n
     gnx = 2 ** (n + 1) + 1
-    gny = world * 2 ** (n + 1) + 1
+    gny = (1 if args.strong else world) * 2 ** (n + 1) + 1
     n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=max(1, n - 4))
     h = 20.0 / 2 ** (n + 1)
     ops = HipOps()
@@ -119,7 +120,7 @@ def main():
     eng._flush_pending()
     eng.ops.end()
     torch.cuda.synchronize()
-    out = {"world": world, "rank": rank, "comm": args.comm, "grid": [gny, gnx], "n_para": n_para,
+    out = {"world": world, "rank": rank, "comm": args.comm, "scaling": "strong" if args.strong else "weak", "grid": [gny, gnx], "n_para": n_para,
            "distributed_levels": eng.n_dist if world > 1 else None, "halo_rows": eng.plan.halo,
            "ms_per_cycle": 1e3 * dt / args.steps, "order": "solve" if args.solve_order else "cycles",
            "host_issue_ms_per_cycle": 1e3 * t_issue / args.steps,
