@@ -596,7 +596,7 @@ class SlabMultigrid:
             if to_rep:
                 self._allgather_b(l + 1)
             elif dist_:
-                items = [(self.b[l + 1], Lc, self.plan.halo - 1)]
+                items = [(self.b[l + 1], Lc, self._b_halo_rows(l + 1))]
                 # its first reader is the next level's descent pass: let that pass hide the exchange
                 if l + 1 < self.n_dist and self._overlaps(l + 1, self.N1 + 2):
                     self._defer_exchange(l + 1, items)
@@ -689,6 +689,14 @@ class SlabMultigrid:
             if to_rep:
                 self._allgather_b(l + 1)
         return src
+
+    def _b_halo_rows(self, l):
+        """Halo rows of level l's right-hand side that its passes read: the descent pass N1 sweeps + residual +
+        restriction deep, the ascent pass N2 sweeps (+ residual) -- or, where the pre-smoothing is recomputed, N1 + N2."""
+        extra = 1 if self.keep_ascent_residuals else 0
+        if self._recomputed(l):
+            return self.N1 + self.N2 + extra
+        return max(self.N1 + 2, self.N2 + extra)
 
     def _recomputed(self, l):
         """Does level l run in the recompute scheme?"""
