@@ -191,9 +191,10 @@ class SlabMultigrid:
             self.rw.append(z(W.ny, W.ld))
         # Several ranks, fused passes: a pass that follows a halo exchange is cut into the rows that depend
         # on owned rows only -- launched first; the exchange runs beside them on a stream of its own --
-        # and the few rows at both slab ends, launched once the halo rows have arrived.  Done on levels
-        # with at least overlap_min_rows rows per rank (None: never); on smaller ones the two extra launches
-        # cost more than the exchange they hide.
+        # and the few rows at both slab ends, launched (as one launch, on that stream) once the halo rows have
+        # arrived.  Done on levels with at least overlap_min_rows rows per rank (None: never); on smaller ones
+        # the interior rows are too short-lived to hide an exchange behind (measured: 4096 and 2048 run alike,
+        # 1024 and below slower).
         self.overlap_min_rows = overlap_min_rows if (world > 1 and self.fused and hasattr(ops, "comm_side")) else None
         self.split_passes = 0  # passes cut this way so far (diagnostics)
         self._pending = None  # (level, exchange items) of a right-hand side whose halo is still to be filled
