@@ -177,6 +177,11 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # Libraries write to the process's standard output too (RCCL prints a version banner there when it makes its
+    # communicator): everything but the one JSON line goes to standard error from here on.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -397,7 +402,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the GPU numbers stand on their own
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
