@@ -192,11 +192,13 @@ int mg_smooth_fused_restrict(const double *b, const double *x_in, double *x_out,
  * The next mg_smooth_fused / mg_smooth_fused_restrict call of the calling host thread produces the rows
  * j2 <= j < j3 as well (j1 <= j2; with a fused restriction also the coarse rows T2 <= T < T3, T1 <= T2, centred on
  * rows of that range), in the same launch and with the same values as a second call with those ranges would.
- * The setting is consumed by that one call, whether it succeeds or not.  For the two ends of a row slab, which a
+ * The setting is consumed by that one call, whether it succeeds or not.  `ny` and `stream` are those of that call:
+ * a setting whose call was never made is refused (and dropped) by the next fused call of the thread when they differ,
+ * instead of adding rows to an unrelated launch.  For the two ends of a row slab, which a
  * pass cut around its halo exchange produces after the interior rows (the slab layout that replaces the four
  * blocks of core/parallel_multigrid.py:39-56): one launch instead of two.
  */
-int mg_fused_also_rows(int64_t j2, int64_t j3, int64_t T2, int64_t T3);
+int mg_fused_also_rows(int64_t j2, int64_t j3, int64_t T2, int64_t T3, int64_t ny, void *stream);
 /* Tuning knobs of mg_smooth_fused: column pairs per lane (1 or 2), rows per tile (0 = automatic). */
 int mg_set_fused_tuning(int unroll, int rows);
 

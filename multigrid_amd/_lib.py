@@ -45,7 +45,7 @@ SIGNATURES = {
     "mg_smooth_fused": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _n, _d, _d, _p, _i, _i, _i, _p], _n),
     "mg_smooth_fused_restrict": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _n, _d, _d, _p, _i, _p, _i, _i,
                                   _i, _i, _i, _i, _i, _i, _i, _p], _n),
-    "mg_fused_also_rows": ([_i, _i, _i, _i], _n),
+    "mg_fused_also_rows": ([_i, _i, _i, _i, _i, _p], _n),
     "mg_set_fused_tuning": ([_n, _n], _n),
     "mg_sor": ([_p, _p, _p, _i, _i, _i, _d, _i, _n, _n, _i, _i, _p], _n),
     "mg_gauss_seidel_rb": ([_p, _p, _i, _i, _i, _i, _i, _d, _n, _i, _i, _p], _n),

@@ -45,15 +45,21 @@ extern "C" int mg_set_fused_tuning(int unroll, int rows)
 }
 
 // A second row range for the next fused pass of the calling thread (mg_fused_also_rows): consumed by that call,
-// whether it succeeds or not.
+// whether it succeeds or not.  It is tied to the launch it was set for by that launch's row count and stream: a
+// setting that was never consumed (its call was not made) is refused by the next fused call instead of adding rows
+// to an unrelated launch.
 static thread_local i64 t_also[4];
+static thread_local i64 t_also_ny = 0;
+static thread_local void *t_also_stream = nullptr;
 static thread_local bool t_also_set = false;
 
-extern "C" int mg_fused_also_rows(i64 j2, i64 j3, i64 T2, i64 T3)
+extern "C" int mg_fused_also_rows(i64 j2, i64 j3, i64 T2, i64 T3, i64 ny, void *stream)
 {
+    t_also_set = false;
     MG_REQUIRE(j2 >= 0 && j2 <= j3 && T2 >= 0 && T2 <= T3, "mg_fused_also_rows: bad ranges [%lld, %lld), [%lld, %lld)", (long long)j2,
                (long long)j3, (long long)T2, (long long)T3);
     t_also[0] = j2, t_also[1] = j3, t_also[2] = T2, t_also[3] = T3;
+    t_also_ny = ny, t_also_stream = stream;
     t_also_set = true;
     return 0;
 }
@@ -82,8 +88,11 @@ static int smooth_fused_impl(const double *b, const double *x_in, double *x_out,
 {
     i64 j2 = 0, j3 = 0, T2 = 0, T3 = 0;
     if (t_also_set) {
-        j2 = t_also[0], j3 = t_also[1], T2 = t_also[2], T3 = t_also[3];
         t_also_set = false;
+        MG_REQUIRE(t_also_ny == ny && t_also_stream == stream,
+                   "mg_smooth_fused: a second row range was set (mg_fused_also_rows) for a launch on an array of %lld rows on "
+                   "another stream or of another height and never consumed; dropped", (long long)t_also_ny);
+        j2 = t_also[0], j3 = t_also[1], T2 = t_also[2], T3 = t_also[3];
     }
     MG_REQUIRE(b && (x_out || coarse_b), "mg_smooth_fused: null array");
     MG_REQUIRE(nbatch >= 1 && nbatch <= 65535, "mg_smooth_fused: nbatch %lld outside 1..65535", (long long)nbatch);

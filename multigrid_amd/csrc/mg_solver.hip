@@ -406,6 +406,7 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
             if (nl > 0) tryx[ntry++] = na - 1;
             int xbest = -1;
             float tspread = 0;
+            if (xo == bk) ntry = 0; // only one fast candidate was seen: nothing to spread
             for (int q = 0; q < ntry && ok; ++q) {
                 const int xi = tryx[q];
                 bool seen = xi == xo || xi == bk;
@@ -421,6 +422,8 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
                 pick[0] = xo, pick[1] = xbest, pick[2] = bk, pick[3] = rk;
             }
         }
+        for (int q = 0; q < 4; ++q) // never two roles in one array: give up the selection rather than alias x and b
+            for (int p = 0; p < q; ++p) ok = ok && pick[p] != pick[q];
         for (int q = 0; q < 4 && ok; ++q) { // xa, xb, b, r
             fin[q] = a[pick[q]];
             a[pick[q]] = nullptr;

@@ -316,12 +316,8 @@ class SlabMultigrid:
             except torch.OutOfMemoryError:
                 torch.cuda.empty_cache()
             later = list(range(n_timed, len(arrs)))
-            xo, bk = pick[0], slow[0]
-            tried = []
-            for xi in [pick[1]] + later[len(later) // 2 :: 3] + later[-1:]:
-                if xi in tried or xi == xo:
-                    continue
-                tried.append(xi)
+            xo, bk, partners = self._spread_plan(pick, slow, later)
+            for xi in partners:
                 t = 0.5 * (time_pass(arrs[bk], arrs[xi], arrs[xo]) + time_pass(arrs[bk], arrs[xo], arrs[xi]))
                 combos += 1
                 if verbose:
@@ -331,6 +327,10 @@ class SlabMultigrid:
             if spread is not None and spread[0] < 0.995 * final:
                 rk = next((k for k in slow[1:] + list(range(len(arrs))) if k not in (xo, spread[1], bk)))
                 final, pick = spread[0], [xo, spread[1], bk, rk]
+        if len(set(pick)) != 4:  # never two roles in one array (x and b in one tensor would make every solve wrong)
+            del arrs, xa, xb, bb
+            torch.cuda.empty_cache()
+            return None
         fin = [arrs[k] for k in pick]
         self.placement = {"candidates": len(ms), "ms_as_output": [round(t, 3) for t in ms], "chosen": pick,
                           "both_kinds_seen": gap, "ms_chosen_combination": round(final, 3), "combinations_timed": combos,
@@ -346,6 +346,20 @@ class SlabMultigrid:
             ops.zero_(a)
         ops.stream.synchronize()
         return fin, cb, xa1
+
+    @staticmethod
+    def _spread_plan(pick, slow, later):
+        """The spread step's candidates: (xo, bk, partners) -- xo the x array that stays (the fastest output), bk the
+        candidate of the slow kind that becomes b, partners the candidates tried as the other x (the second of the
+        four chosen so far, then some of the `later` allocations), none of them xo or bk and none twice.  partners is
+        empty when xo and bk are one candidate (only one fast candidate was seen: nothing to spread)."""
+        xo, bk = pick[0], slow[0]
+        partners = []
+        if xo != bk:
+            for xi in [pick[1]] + later[len(later) // 2 :: 3] + later[-1:]:
+                if xi not in partners and xi not in (xo, bk):
+                    partners.append(xi)
+        return xo, bk, partners
 
     def _place_level1(self, b1, ev, finest_with, t_begin, verbose=False):
         """The same for the one other pass that writes gigabytes: level 1's ascent pass (its x, a quarter of the
@@ -785,9 +799,9 @@ class SlabMultigrid:
         with o.side(after):
             if self.use_graph and self.world > 1:  # on one rank they are part of the cycle graph
                 if self._dead_graph is None:
-                    o.graph_begin()
-                    self._tail_below()
-                    self._dead_graph = o.graph_end()
+                    with o.capture() as cap:
+                        self._tail_below()
+                    self._dead_graph = cap.graph
                 o.graph_launch(self._dead_graph)
             else:
                 self._tail_below()
@@ -836,9 +850,9 @@ class SlabMultigrid:
             self._mid_result = self._middle()
         else:
             if self._mid_graph is None:
-                self.ops.graph_begin()
-                self._mid_result = self._middle()
-                self._mid_graph = self.ops.graph_end()
+                with self.ops.capture() as cap:
+                    self._mid_result = self._middle()
+                self._mid_graph = cap.graph
             self.ops.graph_launch(self._mid_graph)
         # On one rank the side work is enqueued after the rest of the cycle (see _cycle), from this point of
         # the main sequence: captured in that order the graph runs the ascent first and the dead levels beside
@@ -900,9 +914,13 @@ class SlabMultigrid:
                 if (start, store_r) in self._graphs:
                     continue
                 self._cur0 = start
-                self.ops.graph_begin()
-                self._cycle(store_r)
-                self._graphs[(start, store_r)] = (self.ops.graph_end(), self._cur0)
+                try:
+                    with self.ops.capture() as cap:
+                        self._cycle(store_r)
+                except BaseException:
+                    self._cur0, self._r0_stale = cur, stale
+                    raise
+                self._graphs[(start, store_r)] = (cap.graph, self._cur0)
         self._cur0, self._r0_stale = cur, stale
 
     def _reduce_err(self, parity=None):

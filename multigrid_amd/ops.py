@@ -198,7 +198,7 @@ class HipOps:
             # a (batch, slots) accumulator: every problem of the batch has its own max-norm
             nstride = norm.stride(0) if (norm is not None and norm.dim() == 2) else 0
         if also_rows is not None:  # consumed by the call that follows, whatever it returns
-            check(self.L.mg_fused_also_rows(*also_rows))
+            check(self.L.mg_fused_also_rows(*also_rows, ny, self._s))
         if coarse_b is None:
             check(self.L.mg_smooth_fused(*common, prolong_after, h, omega, p(norm), nb, bs, cs, self._s))
         else:
@@ -291,6 +291,36 @@ class HipOps:
             setattr(self, name, stream)
             self._cap_swap = None
         return g
+
+    def graph_abort(self):
+        """End a capture that failed half-way: the recording stops, whatever graph came out of it is destroyed, and
+        the stream the capture's own stream stood in for is back in place.  The error that interrupted the capture
+        is the caller's to re-raise."""
+        if self._cap_swap is None:
+            return
+        g = C.c_void_p()
+        try:
+            if self.L.mg_graph_end(self._s, C.byref(g)) == 0 and g:
+                self.L.mg_graph_destroy(g)
+        finally:
+            name, stream = self._cap_swap
+            setattr(self, name, stream)
+            self._cap_swap = None
+
+    @contextlib.contextmanager
+    def capture(self):
+        """with ops.capture() as cap: ...calls to record...; cap.graph is the executable graph afterwards.  An exception
+        inside the block ends the capture cleanly (graph_abort) before it propagates."""
+        class _Cap:
+            graph = None
+        cap = _Cap()
+        self.graph_begin()
+        try:
+            yield cap
+        except BaseException:
+            self.graph_abort()
+            raise
+        cap.graph = self.graph_end()
 
     def graph_launch(self, g):
         check(self.L.mg_graph_launch(g, self._s))

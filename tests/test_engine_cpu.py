@@ -357,3 +357,113 @@ def test_choose_n_dist_only_proposes_plans_make_plan_accepts():
                     make_plan(gny, 257, n_para, world, 0, halo=halo, n_dist=k)  # must not raise
                     checked += 1
     assert checked > 50
+
+
+# ---------------------------------------------------------------------------------------------------------
+# placement selection (SlabMultigrid._place_finest): the choice logic, driven with scripted timings
+class _FakeArr:
+    def __init__(self, k):
+        self.k = k
+
+    def data_ptr(self):
+        return self.k << 33
+
+
+class _PlacementRig:
+    """Stands in for the engine, its ops and torch.cuda's events inside _place_finest: every candidate allocation
+    is a numbered object, a timed launch costs what `cost(b, x_in, x_out)` says, and no launch may alias two roles."""
+
+    def __init__(self, cost, max_allocs=64):
+        import types
+        self.cost, self.max_allocs = cost, max_allocs
+        self.count, self.last = 0, None
+        lvl = types.SimpleNamespace(ny=32769, ld=32784, nx=32769, t0=1, t1=32768, fix_lo=0, fix_hi=32768, oj=-1, h=1.0)
+        lvc = types.SimpleNamespace(ny=16385, ld=16400, nx=16385, t0=1, t1=16384)
+        self.lv = [lvl, lvc]
+        self.plan = types.SimpleNamespace(levels=[lvl, lvc])
+        self.N2, self.jacobi_omega = 6, 1.0
+        self.ops = self
+        self.device = None
+        self.stream = self
+        self.placement = None
+        for name in ("PLACE_MAX_CANDIDATES", "PLACE_SPREAD_CANDIDATES"):
+            setattr(self, name, getattr(SlabMultigrid, name))
+        self.PLACE_BUDGET_SECONDS = 1e9
+        self._spread_plan = SlabMultigrid._spread_plan
+
+    # ops
+    def zeros(self, rows, ld, batch=None):
+        if rows == 32769:
+            if self.count >= self.max_allocs:
+                raise torch.OutOfMemoryError("scripted")
+            self.count += 1
+            return _FakeArr(self.count - 1)
+        return _FakeArr(-1)
+
+    def norm_slots(self):
+        return _FakeArr(-2)
+
+    def begin(self):
+        pass
+
+    def zero_(self, a):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def smooth_fused(self, b, x_in, x_out, r, crs, *a, **k):
+        assert b is not x_in and b is not x_out and x_in is not x_out, "two roles of one launch in one array"
+        self.last = (b.k, x_in.k, x_out.k)
+
+    def _place_level1(self, *a, **k):
+        return None
+
+
+def _run_placement(monkeypatch, cost, max_allocs=64, budget=1e9, free_bytes=280 << 30):
+    rig = _PlacementRig(cost, max_allocs)
+    rig.PLACE_BUDGET_SECONDS = budget
+
+    class Ev:
+        def __init__(self, enable_timing=False):
+            pass
+
+        def record(self, stream):
+            pass
+
+        def elapsed_time(self, other):
+            return 2.0 * rig.cost(*rig.last)
+
+    monkeypatch.setattr(torch.cuda, "Event", Ev)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free_bytes, 288 << 30))
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    out = SlabMultigrid._place_finest(rig)
+    return rig, out
+
+
+@pytest.mark.parametrize("budget", [0.0, 1e9])
+@pytest.mark.parametrize("n_slow,max_allocs", [(3, 4), (3, 64), (11, 64), (5, 6), (0, 64), (40, 64)])
+def test_placement_selection_never_puts_two_roles_in_one_array(monkeypatch, n_slow, max_allocs, budget):
+    """Scripted timings: the first n_slow candidates are slow as outputs, later ones fast; a launch that reads its
+    right-hand side and x from one stretch of the sequence is a little slower.  Whatever ends the candidate loop
+    (memory, the time budget, enough fast ones), the four chosen arrays are four different allocations and no timed
+    launch ever had one array in two roles (with one fast candidate among slow ones, the spread step used to try the
+    array chosen as b as an x as well)."""
+    def cost(b, xi, xo):
+        return (6.1 if xo < n_slow else 5.4) + (0.1 if (b < n_slow) == (xi < n_slow) else 0.0)
+
+    rig, out = _run_placement(monkeypatch, cost, max_allocs, budget)
+    if out is None:
+        return
+    fin, cb, xa1 = out
+    assert len({a.k for a in fin}) == 4
+    assert rig.placement["chosen"] == [a.k for a in fin]
+
+
+def test_spread_plan_skips_the_arrays_already_in_a_role():
+    plan = SlabMultigrid._spread_plan
+    # b's candidate is also the second x of the four chosen: it is not tried as an x
+    assert plan([3, 0, 1, 2], [0, 1, 2], [4, 5, 6, 7]) == (3, 0, [6, 7])
+    # the fastest output is itself of the slow kind and first in line for b: nothing to spread
+    assert plan([0, 3, 1, 2], [0, 1, 2], [4, 5, 6, 7]) == (0, 0, [])
+    assert plan([5, 4, 6, 7], [0, 1], []) == (5, 0, [4])

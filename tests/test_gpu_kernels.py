@@ -818,7 +818,7 @@ def test_fused_pass_two_row_ranges_in_one_launch(L, shape, mode, rows):
         slots = torch.zeros(L.NORM_SLOTS, dtype=torch.int64, device="cuda")
         for k, (j0, j1) in enumerate(ranges):
             if also is not None and k == 0:
-                L.check(lib.mg_fused_also_rows(also[0], also[1], *(crows(*also) if mode in ("finest", "descent_no_x") else (0, 0))))
+                L.check(lib.mg_fused_also_rows(also[0], also[1], *(crows(*also) if mode in ("finest", "descent_no_x") else (0, 0)), ny, st))
             cs = (dc.data_ptr(), ny, nx, ld, cny, cnx, dc.stride(0))
             if mode == "finest":
                 L.check(lib.mg_smooth_fused_restrict(db.data_ptr(), dx.data_ptr(), out.data_ptr(), rr.data_ptr(), *cs, j0, j1, flo, fhi,
@@ -847,7 +847,7 @@ def test_fused_pass_two_row_ranges_in_one_launch(L, shape, mode, rows):
             assert np.all(two[0][a:e] == 7.0) and not np.all(two[0][e : ny - 1] == 7.0)
         # consumed: the next call covers its own range only
         first_only = run([(2, a)], None)
-        L.check(lib.mg_fused_also_rows(e, ny - 1, 0, 0))
+        L.check(lib.mg_fused_also_rows(e, ny - 1, 0, 0, ny, st))
         L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), padded(x).data_ptr(), None, None, ny, nx, ld, 0, 0, 0, 2, 3, flo,
                                     fhi, oj, 1, 0, h, 1.0, None, 1, 0, 0, st))
         again = run([(2, a)], None)
@@ -859,13 +859,22 @@ def test_fused_pass_two_row_ranges_in_one_launch(L, shape, mode, rows):
         for got, want in zip(empty_first, second_only):
             assert np.array_equal(got, want)
         # rejected: a second range that does not follow the first; the failed call consumes the setting too
-        L.check(lib.mg_fused_also_rows(2, a, 0, 0))
+        L.check(lib.mg_fused_also_rows(2, a, 0, 0, ny, st))
         o = padded(x)
         assert lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), o.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, e, ny - 1, flo, fhi,
                                    oj, 3, 0, h, 1.0, None, 1, 0, 0, st) != 0
         assert b"second row range" in lib.mg_last_error()
         L.check(lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), o.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, e, ny - 1, flo, fhi,
                                     oj, 3, 0, h, 1.0, None, 1, 0, 0, st))
-        assert lib.mg_fused_also_rows(5, 4, 0, 0) != 0
+        assert lib.mg_fused_also_rows(5, 4, 0, 0, ny, st) != 0
+        # a setting whose launch was never made (here: set for an array of another height) is refused by the next
+        # fused call and dropped, instead of adding rows to that unrelated launch
+        L.check(lib.mg_fused_also_rows(e, ny - 1, 0, 0, ny + 2, st))
+        assert lib.mg_smooth_fused(db.data_ptr(), dx.data_ptr(), o.data_ptr(), None, None, ny, nx, ld, 0, 0, 0, 2, a, flo, fhi,
+                                   oj, 3, 0, h, 1.0, None, 1, 0, 0, st) != 0
+        assert b"never consumed" in lib.mg_last_error()
+        stale_dropped = run([(2, a)], None)
+        for got, want in zip(stale_dropped, first_only):
+            assert np.array_equal(got, want)
     finally:
         L.check(lib.mg_set_fused_tuning(2, 0))

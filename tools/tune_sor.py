@@ -40,7 +40,7 @@ def main():
     _lib.check(lib.mg_set_tuning(b"sor_single_wave", 1))
     # grids with more rows than columns (the first whole-domain level of a weak-scaling run over rows): walked along
     # the rows (two rows per lane beyond 65 rows) or along the columns
-    for ny, nx in [(129, 17), (129, 33), (65, 33), (257, 17)]:
+    for ny, nx in [(129, 17), (129, 33), (65, 33), (257, 17), (513, 17), (513, 33), (1025, 17)]:
         ld = pitch(nx)
         b = torch.rand((ny, ld), dtype=torch.float64, device="cuda")
         x, r = torch.zeros_like(b), torch.zeros_like(b)
