@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 7
+#define MG_ABI_VERSION 8
 
 /* flags for the stencil entry points */
 #define MG_FLAG_FINEST 1 /* marks the launches of the finest level; ignored (large outputs get an instantiation of their own, see "stream_min_mib") */
@@ -287,6 +287,49 @@ int mg_graph_begin_own(void **stream_out);
 int mg_graph_end(void *stream, void **graph_exec_out);
 int mg_graph_launch(void *graph_exec, void *stream);
 int mg_graph_destroy(void *graph_exec);
+
+/*
+ * Rank-to-rank data movement of the row-slab layout over RCCL (one process per GPU; the rows travel over xGMI), as raw
+ * RCCL calls enqueued on the caller's stream, in order with its kernels.  The library does not link RCCL: the entry
+ * points are looked up in the RCCL the process has loaded (`rccl_path`: that library's file, or NULL to search the
+ * process), so a communicator made by another component of the process -- torch.distributed's, for one -- can be used.
+ *
+ *   mg_comm_attach     wraps an existing ncclComm_t (borrowed: mg_comm_destroy leaves it alone).  Rank, size and device
+ *                      are the communicator's.
+ *   mg_comm_unique_id / mg_comm_init   a communicator of the library's own: one rank obtains the 128-byte id, hands it to
+ *                      the others by whatever means the caller has, every rank calls mg_comm_init (ncclCommInitRank on
+ *                      the current device); mg_comm_destroy destroys it.
+ *   mg_halo_prepare    fixes the messages of one halo exchange -- blocks of whole rows this rank sends to / receives
+ *                      from its neighbours -- once, as the reference prepares persistent requests per array and level
+ *                      (Buffers.__init__: Send_init / Recv_init, core/parallel_multigrid.py:58-81).  Messages between
+ *                      one pair of ranks are matched in the order given, so every rank lists the arrays in the same
+ *                      order.  A received block must not overlap any other block of the exchange.
+ *   mg_halo_exchange   carries the prepared exchange out on `stream`: one RCCL group of ncclSend / ncclRecv
+ *                      (Buffers.exchange_buffers, :83-97: Startall(recv), pack, Startall(send), Waitall -- no packing here,
+ *                      a row block is contiguous).  Returns when the group is enqueued.
+ *   mg_allgather_rows  out[q * count .. (q+1) * count) <- `in` of rank q, for every rank q: the coarse right-hand side
+ *                      of the first replicated level reaches every rank (gather_blocks, :117-138: four Bcasts and a
+ *                      stitch; row slabs need no stitch).  `in` may be this rank's place inside `out`.
+ *   mg_allreduce_max   element-wise MAX over the ranks of `count` uint64 words, in place: the max-norm accumulator of
+ *                      mg_residual / the fused passes, whose words are bit patterns of |r| (the stop test's allreduce,
+ *                      :342-345, on the norm itself instead of a vote).
+ * All calls of one communicator must come from one host thread at a time with its device current, in the same order
+ * on every rank.  RCCL orders the operations of one communicator among themselves even when they are enqueued on
+ * different streams.
+ */
+typedef struct mg_comm mg_comm;
+typedef struct mg_halo mg_halo;
+int mg_comm_attach(void *nccl_comm, const char *rccl_path, mg_comm **out);
+int mg_comm_unique_id(const char *rccl_path, void *id128);
+int mg_comm_init(const void *id128, int rank, int world, const char *rccl_path, mg_comm **out);
+int mg_comm_info(mg_comm *c, int *rank, int *world, int *rccl_version);
+int mg_comm_destroy(mg_comm *c);
+int mg_halo_prepare(mg_comm *c, int nsend, double *const *send_ptr, const int64_t *send_count, const int *send_peer,
+                    int nrecv, double *const *recv_ptr, const int64_t *recv_count, const int *recv_peer, mg_halo **out);
+int mg_halo_exchange(mg_halo *h, void *stream);
+int mg_halo_destroy(mg_halo *h);
+int mg_allgather_rows(mg_comm *c, const double *in, double *out, int64_t count, void *stream);
+int mg_allreduce_max(mg_comm *c, uint64_t *words, int64_t count, void *stream);
 
 /*
  * The whole solver behind a handle: Multigrid.__init__ / Multigrid.solve of

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MG_HIP_LIB: another build of the library (A/B experiments with tools/); the default is the one beside this file
 LIB_PATH = os.environ.get("MG_HIP_LIB") or os.path.join(_HERE, "libmg_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 NORM_SLOTS = 64
 FLAG_FINEST = 1
 SOR_LEXICOGRAPHIC = 0
@@ -59,6 +59,17 @@ SIGNATURES = {
     "mg_graph_end": ([_p, C.POINTER(_p)], _n),
     "mg_graph_launch": ([_p, _p], _n),
     "mg_graph_destroy": ([_p], _n),
+    "mg_comm_attach": ([_p, C.c_char_p, C.POINTER(_p)], _n),
+    "mg_comm_unique_id": ([C.c_char_p, _p], _n),
+    "mg_comm_init": ([_p, _n, _n, C.c_char_p, C.POINTER(_p)], _n),
+    "mg_comm_info": ([_p, C.POINTER(_n), C.POINTER(_n), C.POINTER(_n)], _n),
+    "mg_comm_destroy": ([_p], _n),
+    "mg_halo_prepare": ([_p, _n, C.POINTER(_p), C.POINTER(_i), C.POINTER(_n), _n, C.POINTER(_p), C.POINTER(_i), C.POINTER(_n),
+                         C.POINTER(_p)], _n),
+    "mg_halo_exchange": ([_p, _p], _n),
+    "mg_halo_destroy": ([_p], _n),
+    "mg_allgather_rows": ([_p, _p, _p, _i, _p], _n),
+    "mg_allreduce_max": ([_p, _p, _i, _p], _n),
     "mg_solver_create": ([_i, _i, _n, _d, _n, C.POINTER(_p)], _n),
     "mg_solver_destroy": ([_p], _n),
     "mg_solver_set": ([_p, C.c_char_p, _d], _n),

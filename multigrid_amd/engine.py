@@ -50,7 +50,7 @@ class SlabMultigrid:
                  store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
                  recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=False,
                  overlap_min_rows=4096, batch_stop="max", fine_smoother="jacobi", comm=None,
-                 recompute_last_distributed=True):
+                 recompute_last_distributed=True, dist_levels=None, t_round=None, gather_bw=None):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -82,8 +82,12 @@ class SlabMultigrid:
         n_dist = n_para
         if world > 1:
             R0 = (gny - 1) // world
-            if dist_min_rows is None:
-                n_dist = choose_n_dist(gny, gnx, n_para, world, halo)
+            if dist_levels is not None:  # the caller's choice; make_plan refuses what cannot be cut
+                n_dist = max(1, min(n_para, int(dist_levels)))
+            elif dist_min_rows is None:
+                # t_round, gather_bw: measured cost of one exchange round (s) and rate of the all-gather (B/s) on this
+                # machine, where the caller has them (bench.py measures both); None = the cost model's defaults
+                n_dist = choose_n_dist(gny, gnx, n_para, world, halo, t_round=t_round, gather_bw=gather_bw)
             else:
                 n_dist = max(1, sum(1 for l in range(n_para) if (R0 >> l) >= max(dist_min_rows, halo)))
         self.n_dist = n_dist
@@ -1052,6 +1056,9 @@ class SlabMultigrid:
         return err
 
     def close(self):
+        self._xchg_cache = {}
+        if getattr(self.comm, "close", None) is not None:
+            self.comm.close()
         for g, _ in self._graphs.values():
             self.ops.graph_destroy(g)
         self._graphs = {}

@@ -219,15 +219,27 @@ def choose_n_para(gny, gnx, world=1, at_least=1):
         n_para += 1
 
 
-def choose_n_dist(gny, gnx, n_para, world, halo, t_round=110e-6, gather_bw=100e9, stream_rate=4.5e12, bytes_per_point=36):
+T_ROUND_DEFAULT = 110e-6    # one exchange round on the cycle's critical path (s), unless measured
+GATHER_BW_DEFAULT = 100e9   # rate at which an all-gathered array arrives at a rank (B/s), unless measured
+
+
+def choose_n_dist(gny, gnx, n_para, world, halo, t_round=None, gather_bw=None, stream_rate=4.5e12, bytes_per_point=36):
     """How many of the Jacobi levels (the finest ones) to cut into slabs, by a cost model of one V-cycle:
       * every distributed level costs two exchange rounds (t_round each: what a batch of row
-        sends/receives costs the host on RCCL; the rows themselves are a few hundred KB);
+        sends/receives adds to the cycle where no pass is long enough to hide it; the rows themselves
+        are a few hundred KB);
       * the first replicated level's right-hand side is all-gathered: its bytes x (world-1)/world
         arrive at every rank at gather_bw (xGMI is point-to-point: a ring moves ~one link's worth);
       * every replicated level is computed by all ranks: its points x bytes_per_point at stream_rate.
+    t_round / gather_bw: measured values (bench.py measures both at start-up); None = the environment's
+    MG_T_ROUND_US / MG_GATHER_GBPS, else the defaults above.  Every rank must pass the same values.
     Returns the k in 1..n_para with the least cost among those make_plan accepts (slabs of at least `halo` rows,
     rows per rank divisible by 2**k)."""
+    import os
+    if t_round is None:
+        t_round = float(os.environ["MG_T_ROUND_US"]) * 1e-6 if os.environ.get("MG_T_ROUND_US") else T_ROUND_DEFAULT
+    if gather_bw is None:
+        gather_bw = float(os.environ["MG_GATHER_GBPS"]) * 1e9 if os.environ.get("MG_GATHER_GBPS") else GATHER_BW_DEFAULT
     R0 = (gny - 1) // world
     best, best_cost = 1, None
     for k in range(1, n_para + 1):

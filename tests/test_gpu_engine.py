@@ -358,6 +358,34 @@ def test_converged_solution_matches_direct_solve():
         eng.close()
 
 
+def test_converged_solution_matches_direct_solve_at_513():
+    """The reference's own size (513 x 513, n = 8, n_para = 4, its test driver's right-hand side): with the textbook
+    ascent through the whole-domain levels and damped sweeps (the reference's undamped schedule stalls on the
+    checkerboard mode long before) the cycle converges to rounding level, and the solution equals a sparse direct
+    solve of the same 5-point system to 1e-10 relative L2."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    n, n_para = 8, 4
+    b0, h = vortex_rhs(n)
+    b0 = b0.copy()
+    b0[0] = b0[-1] = 0
+    b0[:, 0] = b0[:, -1] = 0
+    N = 2 ** (n + 1) + 1
+    m = N - 2
+    T = sp.diags([np.ones(m - 1), -2 * np.ones(m), np.ones(m - 1)], [-1, 0, 1])
+    A = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))) / h ** 2
+    x_direct = np.zeros((N, N))
+    x_direct[1:-1, 1:-1] = spla.spsolve(A.tocsc(), b0[1:-1, 1:-1].ravel()).reshape(m, m)
+    eng = _make(N, N, n_para, h, 0.0, b0, fix_coarse_ascent=True, jacobi_omega=0.8)
+    eng.presmooth()
+    errs = eng.cycles(60)
+    x = _rows(eng, eng.x0)
+    rel = np.linalg.norm(x - x_direct) / np.linalg.norm(x_direct)
+    assert rel < 1e-10, (errs[-1], rel)
+    assert errs[-1] < 1e-8 * errs[0]
+    eng.close()
+
+
 @pytest.mark.parametrize("gny,gnx,n_para", [(129, 129, 3), (1025, 1025, 4), (513, 2049, 5)], ids=str)
 @pytest.mark.parametrize("graph,recompute,fused", [(True, True, True), (False, False, True), (True, False, False)])
 def test_damped_jacobi_equals_oracle(gny, gnx, n_para, graph, recompute, fused):

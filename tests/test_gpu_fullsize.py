@@ -263,3 +263,135 @@ def test_two_ranks_at_the_benchmark_slab_size_equal_one_rank():
         assert np.array_equal(xs, x[rows].cpu().numpy())
         assert np.array_equal(rs, r[rows].cpu().numpy())
     one.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The grids of the multi-GPU configurations cut into as many slabs as they name, every rank a process of its own
+# sharing the one GPU (gloo, messages staged through the host), values checked.
+
+def _scratch_dir():
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    return tempfile.mkdtemp(prefix="mg_slabs_", dir=base)
+
+
+def _slab_worker(rank, world, port, n, n_para, cycles, ddir, kw, q):  # started by tests.mp_util.run_ranks
+    """Rank `rank` of `world` on the (2^(n+1)+1)^2 grid cut into `world` slabs.  ddir holds b.npy (the global right-hand
+    side) and, when the caller has them, x.npy / r.npy (what every rank's rows must equal bit for bit)."""
+    from tests.mp_util import rank_watchdog
+    rank_watchdog(int(os.environ.get("MG_TEST_RANK_WATCHDOG", "170")))
+    import torch
+    import torch.distributed as dist
+    from multigrid_amd.engine import SlabMultigrid
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N = 2 ** (n + 1) + 1
+        eng = SlabMultigrid(N, N, n_para, 20.0 / 2 ** (n + 1), 0.0, world=world, rank=rank, eager_dead_levels=True, **kw)
+        R = eng.plan.levels[0].rows
+        a, e = eng.owned_rows()
+        g0 = rank * R
+        b = np.load(os.path.join(ddir, "b.npy"), mmap_mode="r")
+        eng.set_b_rows(torch.from_numpy(np.ascontiguousarray(b[g0 : g0 + (e - a)])).cuda())
+        eng.presmooth()
+        before = eng.comm.rounds
+        errs = eng.cycles(cycles)
+        rounds_ok = eng.comm.rounds - before == cycles * eng.rounds_per_cycle()
+        x, r = eng.local_rows(eng.x0), eng.local_rows(eng.r0)
+        same = None
+        if os.path.exists(os.path.join(ddir, "x.npy")):
+            xr = np.load(os.path.join(ddir, "x.npy"), mmap_mode="r")
+            rr = np.load(os.path.join(ddir, "r.npy"), mmap_mode="r")
+            same = (_equal_rows(x, xr[g0 : g0 + (e - a)]), _equal_rows(r, rr[g0 : g0 + (e - a)]))
+        # rows at the slab ends, next to them, around the cuts of the passes and inside
+        m = e - a
+        picks = sorted({t for t in (0, 1, 2, 7, 8, 9, 11, 12, 13, 15, 16, 17, 18, 19, 23, 24, 25, 100, m // 2, m - 26, m - 25, m - 20, m - 19,
+                                    m - 18, m - 17, m - 16, m - 14, m - 13, m - 12, m - 9, m - 8, m - 3, m - 2, m - 1) if 0 <= t < m})
+        q.put((rank, errs, eng.n_dist, eng.split_passes, rounds_ok, same, [g0 + t for t in picks], x[picks].cpu().numpy(),
+               r[picks].cpu().numpy()))
+        dist.barrier()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_16385_grid_in_eight_slabs_equals_oracle():
+    """16385 x 16385 cut into EIGHT slabs of 2048 rows (nine Jacobi levels, as many of them distributed as the cost
+    model chooses, a 33 x 33 first whole-domain level): every rank's per-cycle norms, all of x and all of r equal
+    the undecomposed oracle bit for bit, with the expected number of communication rounds."""
+    import shutil
+    import torch
+    from tests.mp_util import run_ranks
+    n, n_para, world, cycles = 13, 9, 8, 2
+    one = _engine(n, n_para, eager_dead_levels=True)  # for the right-hand side (built on the device)
+    N = one.plan.gnx
+    b = one.local_rows(one.b0).cpu().numpy()
+    one.close()
+    del one
+    torch.cuda.empty_cache()
+    ref = oracle.GlobalSolver(N, N, n_para, 20.0 / 2 ** (n + 1), 0.0)
+    ref.b[:] = b
+    ref.solve(ncycles=cycles)
+    ddir = _scratch_dir()
+    try:
+        np.save(os.path.join(ddir, "b.npy"), b)
+        np.save(os.path.join(ddir, "x.npy"), ref.x)
+        np.save(os.path.join(ddir, "r.npy"), ref.r)
+        out = run_ranks(_slab_worker, world, (n, n_para, cycles, ddir, {}), timeout=220)
+    finally:
+        shutil.rmtree(ddir, ignore_errors=True)
+    for rank in range(world):
+        errs, n_dist, cut, rounds_ok, same, rows, xs, rs = out[rank]
+        assert errs == ref.err_hist.tolist(), rank
+        assert same == (True, True), rank
+        assert rounds_ok and 1 <= n_dist <= n_para, rank
+        assert np.array_equal(xs, ref.x[rows]) and np.array_equal(rs, ref.r[rows])
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_32769_grid_in_slabs_equals_one_rank(world):
+    """32769 x 32769 (ten Jacobi levels) cut into 4 and into 8 slabs, the partitions of the strong-scaling runs: every
+    rank's per-cycle norms equal those of the engine on one rank (itself equal to the oracle at this size,
+    test_engine_equals_oracle_at_32769), and so do rows of x and r at the slab ends, next to them, around the cuts of
+    the passes and inside; the largest levels' passes are cut around their halo exchange."""
+    import shutil
+    import torch
+    from tests.mp_util import run_ranks
+    n, n_para, cycles = 14, 10, 2
+    one = _engine(n, n_para, eager_dead_levels=True)
+    ddir = _scratch_dir()
+    try:
+        brows = one.local_rows(one.b0)
+        N = one.plan.gnx
+        bm = np.lib.format.open_memmap(os.path.join(ddir, "b.npy"), mode="w+", dtype=np.float64, shape=(N, N))
+        for a in range(0, N, 2048):
+            bm[a : a + 2048] = brows[a : a + 2048].cpu().numpy()
+        bm.flush()
+        del bm
+        one.presmooth()
+        errs1 = one.cycles(cycles)
+        x1, r1 = one.local_rows(one.x0), one.local_rows(one.r0)
+        R = (N - 1) // world
+        m = R
+        want = {}
+        for rank in range(world):
+            mm = m + (1 if rank == world - 1 else 0)
+            picks = sorted({t for t in (0, 1, 2, 7, 8, 9, 11, 12, 13, 15, 16, 17, 18, 19, 23, 24, 25, 100, mm // 2, mm - 26, mm - 25, mm - 20,
+                                        mm - 19, mm - 18, mm - 17, mm - 16, mm - 14, mm - 13, mm - 12, mm - 9, mm - 8, mm - 3, mm - 2, mm - 1)
+                            if 0 <= t < mm})
+            rows = [rank * R + t for t in picks]
+            want[rank] = (rows, x1[rows].cpu().numpy(), r1[rows].cpu().numpy())
+        one.close()
+        del one, x1, r1, brows
+        torch.cuda.empty_cache()
+        out = run_ranks(_slab_worker, world, (n, n_para, cycles, ddir, {}), timeout=240)
+    finally:
+        shutil.rmtree(ddir, ignore_errors=True)
+    for rank in range(world):
+        errs, n_dist, cut, rounds_ok, same, rows, xs, rs = out[rank]
+        assert errs == errs1, rank
+        assert rounds_ok and n_dist >= 2 and cut >= 1 + cycles, (rank, n_dist, cut)
+        assert rows == want[rank][0]
+        assert np.array_equal(xs, want[rank][1]) and np.array_equal(rs, want[rank][2]), rank

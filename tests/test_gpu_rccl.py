@@ -1,7 +1,8 @@
-"""The direct (RCCL) branch of SlabComm on a one-rank `nccl` group: RCCL refuses two ranks on one
+"""The RCCL branches of SlabComm on a one-rank `nccl` group: RCCL refuses two ranks on one
 device, so the calls the multi-GPU engine makes -- a batch of row sends/receives, the all-gather of
 whole rows into a padded array, the integer MAX-reduction of the norm slots -- are issued here with
-the rank as its own neighbour, on views shaped like the engine's.  Checks that the backend accepts
+the rank as its own neighbour, on views shaped like the engine's: once through torch.distributed ("direct")
+and once as the raw RCCL calls libmg_hip.so makes on the group's communicator ("native", the engine's default).  Checks that the backend accepts
 the tensors as they are (views, dtypes) and moves the right bytes, and that the engine's hipGraph
 capture and replay work in a process that holds an RCCL communicator.  Marked gpu."""
 import os
@@ -30,50 +31,74 @@ def _worker(port, q):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        from multigrid_amd.comm import SlabComm
+        from multigrid_amd.comm import SlabComm, torch_nccl_comm
         from multigrid_amd.ops import HipOps
         ops = HipOps(torch.device("cuda", 0))
-        comm = SlabComm(ops, None, 1, 0)
-        assert not comm.staged
         H, rows, ld = 12, 64, 144
-        ops.begin()
-        with ops.ctx():
-            x = torch.arange((rows + 2 * H) * ld, dtype=torch.float64, device="cuda").view(rows + 2 * H, ld)
-            want = x.clone()
-            # the engine's exchange: own rows next to the halo go out, the halo rows come in
-            # (here the lower neighbour's send is this rank's own, so halo_lo <- top own rows and so on)
-            sends = [(x[H:2 * H].view(-1), 0), (x[rows:rows + H].view(-1), 0)]
-            recvs = [(x[rows + H:].view(-1), 0), (x[:H].view(-1), 0)]
-            want[rows + H:] = want[H:2 * H]
-            want[:H] = want[rows:rows + H]
-        batch = comm.prepare(sends, recvs)
-        comm.run(batch)
-        comm.run(batch)  # a prepared batch is issued every cycle
-        # the same batch on the communication stream, beside a kernel of the main sequence (split passes)
-        with ops.ctx():
-            scratch = torch.ones(1 << 20, dtype=torch.float64, device="cuda")
-        ready = ops.mark()
-        ops.zero_(scratch)
-        with ops.comm_side(ready):
+
+        def exercise(comm):
+            """The engine's three communication patterns on `comm`, the rank being its own neighbour."""
+            ops.begin()
+            with ops.ctx():
+                x = torch.arange((rows + 2 * H) * ld, dtype=torch.float64, device="cuda").view(rows + 2 * H, ld)
+                want = x.clone()
+                # the engine's exchange: own rows next to the halo go out, the halo rows come in
+                # (here the lower neighbour's send is this rank's own, so halo_lo <- top own rows and so on)
+                sends = [(x[H:2 * H].view(-1), 0), (x[rows:rows + H].view(-1), 0)]
+                recvs = [(x[rows + H:].view(-1), 0), (x[:H].view(-1), 0)]
+                want[rows + H:] = want[H:2 * H]
+                want[:H] = want[rows:rows + H]
+            batch = comm.prepare(sends, recvs)
             comm.run(batch)
-        ops.comm_join()
+            comm.run(batch)  # a prepared batch is issued every cycle
+            # the same batch on the communication stream, beside a kernel of the main sequence (split passes)
+            with ops.ctx():
+                scratch = torch.ones(1 << 20, dtype=torch.float64, device="cuda")
+            ready = ops.mark()
+            ops.zero_(scratch)
+            with ops.comm_side(ready):
+                comm.run(batch)
+            ops.comm_join()
+            with ops.ctx():
+                inp = x[H:H + rows]
+                out = torch.zeros(rows + 5, ld, dtype=torch.float64, device="cuda")
+            comm.allgather_rows(out[2:2 + rows], inp)
+            with ops.ctx():
+                slots = ops.norm_slots()
+                slots[3] = 0x7FF8000000000000  # a NaN's bit pattern stays the maximum
+                slots[5] = 12345
+                before = slots.clone()
+            comm.allreduce_max(slots)
+            ops.stream.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                comm.run(batch)
+            ops.stream.synchronize()
+            per_round = (time.perf_counter() - t0) / 50
+            ops.end()
+            ok = (bool(torch.equal(x, want)) and bool(scratch.eq(0).all()), bool(torch.equal(out[2:2 + rows], inp)),
+                  bool(out[:2].eq(0).all() and out[2 + rows:].eq(0).all()), bool(torch.equal(slots, before)))
+            return ok, per_round, batch, scratch, out, inp
+
+        comm = SlabComm(ops, None, 1, 0)  # torch.distributed's calls (one rank: nothing attached)
+        assert not comm.staged and comm.native is None
+        ok_direct, per_round, batch, scratch, out, inp = exercise(comm)
+        # the same through the library's raw RCCL calls on the group's communicator
+        ncomm = SlabComm(ops, None, 1, 0)
+        ncomm._attach(torch_nccl_comm(None, ops.device))
+        assert ncomm.native is not None and ncomm.mode == "native"
+        ok_native, per_round_native, nbatch, _, _, _ = exercise(ncomm)
+        # a message table the library must refuse: a received block that overlaps a sent one; a peer outside the communicator
+        from multigrid_amd._lib import MgError
         with ops.ctx():
-            inp = x[H:H + rows]
-            out = torch.zeros(rows + 5, ld, dtype=torch.float64, device="cuda")
-        comm.allgather_rows(out[2:2 + rows], inp)
-        with ops.ctx():
-            slots = ops.norm_slots()
-            slots[3] = 0x7FF8000000000000  # a NaN's bit pattern stays the maximum
-            slots[5] = 12345
-            before = slots.clone()
-        comm.allreduce_max(slots)
-        ops.stream.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(50):
-            comm.run(batch)
-        ops.stream.synchronize()
-        per_round = (time.perf_counter() - t0) / 50
-        ops.end()
+            y = torch.zeros(4 * ld, dtype=torch.float64, device="cuda")
+        refused = 0
+        for sends_, recvs_ in (([(y[: 2 * ld], 0)], [(y[ld : 3 * ld], 0)]), ([(y[:ld], 1)], [(y[ld : 2 * ld], 0)])):
+            try:
+                ncomm.prepare(sends_, recvs_)
+            except MgError:
+                refused += 1
+        ok_native = ok_native + (refused == 2,)
         # capturing and replaying the cycle graphs while the RCCL communicator and its helper threads are alive
         import numpy as np
         from multigrid_amd.engine import SlabMultigrid
@@ -121,7 +146,8 @@ def _worker(port, q):
         for world, rank in ((2, 0), (4, 2), (8, 7)):
             gny, gnx = world * 1024 + 1, 1025
             ops2 = HipOps(torch.device("cuda", 0))
-            lc = LoopbackComm(ops2, world, rank, rccl=True)
+            lc = LoopbackComm(ops2, world, rank, rccl=True, native=world != 4)  # the library's raw RCCL calls; torch's once
+            assert lc.mode == ("native" if world != 4 else "direct")
             eng = SlabMultigrid(gny, gnx, 6, 0.01, 0.0, ops=ops2, world=world, rank=rank, comm=lc, eager_dead_levels=True,
                                 overlap_min_rows=1, dist_min_rows=64, max_cycles=3)
             a, e = eng.owned_rows()
@@ -137,9 +163,8 @@ def _worker(port, q):
             eng.close()
         print("loopback engine runs:", engine_runs, flush=True)
         graphs_ok = graphs_ok and all(r[0] == 3 and r[1] and r[2] == r[3] and r[4] and r[5] and r[6] for r in engine_runs)
-        ok = (bool(torch.equal(x, want)) and bool(scratch.eq(0).all()), bool(torch.equal(out[2:2 + rows], inp)), bool(out[:2].eq(0).all() and out[2 + rows:].eq(0).all()),
-              bool(torch.equal(slots, before)), graphs_ok)
-        q.put((ok, per_round))
+        ncomm.close()
+        q.put((ok_direct + (graphs_ok,), ok_native, per_round, per_round_native))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -152,11 +177,13 @@ def test_slabcomm_direct_branch_on_one_rank_rccl_group():
     p = ctx.Process(target=_worker, args=(_free_port(), q))
     p.start()
     try:
-        ok, per_round = q.get(timeout=150)
+        ok, ok_native, per_round, per_round_native = q.get(timeout=150)
     finally:
         p.join(timeout=30)
         if p.is_alive():
             p.kill()
-    print(f"one exchange round on a one-rank RCCL group: {per_round * 1e6:.0f} us")
+    print(f"one exchange round on a one-rank RCCL group: {per_round * 1e6:.0f} us through torch.distributed, "
+          f"{per_round_native * 1e6:.0f} us as raw RCCL calls of the library")
     assert ok == (True, True, True, True, True)
+    assert ok_native == (True, True, True, True, True)
     assert p.exitcode == 0

@@ -4,24 +4,33 @@ would receive from the other neighbour (the rows are shaped alike), the all-gath
 rank's own, the MAX-reduction sees one rank.  Values are therefore meaningless; the calls, their order, their sizes,
 the streams they run on and their cost on the host and on the GPU are those of the real job.
 
-rccl=True: the engine's own torch.distributed calls on a one-rank `nccl` group (which the caller has initialised),
-every peer mapped to rank 0.  rccl=False: plain device copies on the stream the exchange would run on.
+rccl=True: the engine's own communication calls on a one-rank `nccl` group (which the caller has initialised),
+every peer mapped to rank 0 -- native=True (default): the raw RCCL calls libmg_hip.so makes on the engine's streams
+(mg_halo_exchange, mg_allgather_rows, mg_allreduce_max on the group's communicator); native=False: torch.distributed's.
+rccl=False: plain device copies on the stream the exchange would run on.
 Used by tools/rank_rehearsal.py and tests/test_gpu_rccl.py."""
 import torch.distributed as dist
 
-from multigrid_amd.comm import SlabComm
+from multigrid_amd.comm import SlabComm, torch_nccl_comm
 
 
 class LoopbackComm(SlabComm):
-    def __init__(self, ops, world, rank, rccl=True):
+    def __init__(self, ops, world, rank, rccl=True, native=True):
         self.ops, self.group, self.world, self.rank = ops, None, world, rank
         self.staged, self.rounds = False, 0
+        self.native, self._halos, self.mode = None, [], "copy"
         self.rccl = rccl
         if self.rccl:
+            self.mode = "direct"
             t = ops.zeros(1, 1)
             self.allreduce_max(t.view(-1))
+            if native:
+                self._attach(torch_nccl_comm(None, ops.device))
 
     def _peer(self, r):
+        return 0
+
+    def _native_peer(self, r):
         return 0
 
     def prepare(self, sends, recvs):
@@ -51,8 +60,13 @@ class LoopbackComm(SlabComm):
         self.rounds += 1
         R = inp.shape[0]
         own = out[self.rank * R : (self.rank + 1) * R]
+        if self.native is not None:  # a one-rank all-gather: the rank's rows into its place
+            from multigrid_amd._lib import check
+            check(self._L.mg_allgather_rows(self.native, inp.data_ptr(), own.data_ptr(), inp.numel(), self.ops._s))
         with self.ops.ctx():
-            if self.rccl:
+            if self.native is not None:
+                pass
+            elif self.rccl:
                 dist.all_gather_into_tensor(own.view(-1), inp.view(-1))
             else:
                 own.copy_(inp)
@@ -61,6 +75,8 @@ class LoopbackComm(SlabComm):
                     out[q * R : (q + 1) * R].copy_(own)
 
     def allreduce_max(self, t):
+        if self.native is not None:
+            return SlabComm.allreduce_max(self, t)
         if self.rccl:
             with self.ops.ctx():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -42,7 +42,9 @@ def main():
     ap.add_argument("--jacobi-levels", dest="n_para", type=int, default=0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "copy"])
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "rccl-torch", "copy"],
+                    help="rccl: raw RCCL calls made by libmg_hip.so on the engine's streams (the default of the N > 1 engine); "
+                         "rccl-torch: the same exchanges through torch.distributed; copy: device copies, no RCCL")
     ap.add_argument("--no-tune-placement", action="store_true")
     ap.add_argument("--solve-order", action="store_true",
                     help="read every cycle's norm before the next cycle is issued, as solve() must")
@@ -64,7 +66,7 @@ def main():
     world = args.world
     rank = world // 2 if args.rank is None else args.rank
     torch.cuda.set_device(0)
-    if args.comm == "rccl":
+    if args.comm != "copy":
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -79,7 +81,7 @@ def main():
     n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=max(1, n - 4))
     h = 20.0 / 2 ** (n + 1)
     ops = HipOps()
-    comm = LoopbackComm(ops, world, rank, rccl=args.comm == "rccl") if world > 1 else None
+    comm = LoopbackComm(ops, world, rank, rccl=args.comm != "copy", native=args.comm == "rccl") if world > 1 else None
     extra = json.loads(args.engine_args)
     eng = SlabMultigrid(gny, gnx, n_para, h, 0.025, ops=ops, world=world, rank=rank, comm=comm, eager_dead_levels=True,
                         tune_placement=not args.no_tune_placement, overlap_min_rows=args.overlap_min_rows,
@@ -120,7 +122,7 @@ def main():
     eng._flush_pending()
     eng.ops.end()
     torch.cuda.synchronize()
-    out = {"world": world, "rank": rank, "comm": args.comm, "scaling": "strong" if args.strong else "weak", "grid": [gny, gnx], "n_para": n_para,
+    out = {"world": world, "rank": rank, "comm": args.comm, "comm_mode": comm.mode if comm else None, "scaling": "strong" if args.strong else "weak", "grid": [gny, gnx], "n_para": n_para,
            "distributed_levels": eng.n_dist if world > 1 else None, "halo_rows": eng.plan.halo,
            "ms_per_cycle": 1e3 * dt / args.steps, "order": "solve" if args.solve_order else "cycles",
            "host_issue_ms_per_cycle": 1e3 * t_issue / args.steps,
@@ -129,7 +131,7 @@ def main():
            "placement": eng.placement}
     print(json.dumps(out), flush=True)
     eng.close()
-    if args.comm == "rccl":
+    if args.comm != "copy":
         dist.destroy_process_group()
 
 
