@@ -81,6 +81,16 @@ def parse():
                          "(e.g. --batch 1024 --exp 7 --jacobi-levels 4); not the headline workload")
     ap.add_argument("--jacobi-omega", type=float, default=1.0,
                     help="damping of the Jacobi sweeps (1 = the reference's sweep; an option of this build)")
+    ap.add_argument("--dist-levels", type=int, default=0,
+                    help="N > 1: how many of the Jacobi levels (the finest ones) are cut into slabs; 0 = the cost model's choice "
+                         "(levels.choose_n_dist) from the exchange round and the all-gather timed at start-up "
+                         "(or MG_T_ROUND_US / MG_GATHER_GBPS from the environment)")
+    ap.add_argument("--overlap-min-rows", type=int, default=4096,
+                    help="N > 1: passes of levels with at least this many rows per rank are cut into interior rows and slab ends "
+                         "around their halo exchange")
+    ap.add_argument("--no-comm-calibration", action="store_true",
+                    help="N > 1: do not time an exchange round and an all-gather at start-up; the cost model's defaults decide")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host <-> device copy of one finest-level array")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages messages through the host: lets several ranks share one GPU (rehearsal only)")
     return ap.parse_args()
@@ -175,6 +185,93 @@ def cpu_baseline(args):
     return out
 
 
+def calibrate_comm(torch, dist, world, rank, gnx, halo):
+    """Time what the distribution cost model prices, on this machine, before the engine is built: one halo exchange
+    round of the engine's shape (`halo` rows of a gnx-wide array to and from each neighbour) and one all-gather of
+    an 8 MiB slab per rank, each issued alone on the stream (GPU time per call by HIP events, host time per call by
+    the clock).  Every rank gets the same numbers: the slowest rank's round, the slowest all-gather."""
+    from multigrid_amd.comm import SlabComm
+    from multigrid_amd.levels import pitch
+    from multigrid_amd.ops import HipOps
+    ops = HipOps()
+    comm = SlabComm(ops, None, world, rank)
+    ld = pitch(gnx)
+    R = 64
+    arr = ops.zeros(R + 2 * halo, ld)
+    sends, recvs = [], []
+    if rank > 0:
+        sends.append((arr[halo : 2 * halo].view(-1), rank - 1))
+        recvs.append((arr[:halo].view(-1), rank - 1))
+    if rank < world - 1:
+        sends.append((arr[R : R + halo].view(-1), rank + 1))
+        recvs.append((arr[R + halo :].view(-1), rank + 1))
+    batch = comm.prepare(sends, recvs)
+    grows = max(1, (8 << 20) // (ld * 8))
+    gin, gout = ops.zeros(grows, ld), ops.zeros(world * grows, ld)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def timed(fn, reps):
+        ops.begin()
+        fn()
+        fn()
+        ops.stream.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        ev[0].record(ops.stream)
+        for _ in range(reps):
+            fn()
+        host = (time.perf_counter() - t0) / reps
+        ev[1].record(ops.stream)
+        ops.stream.synchronize()
+        ops.end()
+        return host, ev[0].elapsed_time(ev[1]) * 1e-3 / reps
+
+    round_host, round_gpu = timed(lambda: comm.run(batch), 20)
+    gather_host, gather_gpu = timed(lambda: comm.allgather_rows(gout, gin), 10)
+    t = torch.tensor([round_host, round_gpu, gather_host, gather_gpu], dtype=torch.float64,
+                     device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    round_host, round_gpu, gather_host, gather_gpu = (float(v) for v in t)
+    gbytes = grows * ld * 8 * (world - 1)  # what arrives at one rank
+    mode = comm.mode
+    comm.close()
+    return {"comm_mode": mode, "round_host_us": 1e6 * round_host, "round_gpu_us": 1e6 * round_gpu,
+            "round_bytes_per_neighbour": halo * ld * 8, "allgather_host_us": 1e6 * gather_host, "allgather_gpu_us": 1e6 * gather_gpu,
+            "allgather_bytes_received": gbytes, "allgather_gbps": gbytes / max(gather_gpu, 1e-9) / 1e9,
+            # what choose_n_dist is given: a round costs the cycle whichever is longer, issuing it or running it
+            "t_round_us": 1e6 * max(round_host, round_gpu), "gather_gbps": gbytes / max(gather_gpu, gather_host, 1e-9) / 1e9}
+
+
+def pcie_copy(torch, eng):
+    """Host <-> device copy of ONE finest-level array, measured: what a caller whose arrays live in host memory pays
+    per array on top of the cycles (the reference's level-0 arrays are the caller's own numpy arrays,
+    core/parallel_multigrid.py:196-198).  The owned rows of b go device -> host through a pinned staging buffer of
+    at most 1 GiB, chunk by chunk; the same number of bytes then goes host -> device into a scratch array."""
+    rows = eng.local_rows(eng.b0)
+    ny, nx = rows.shape[-2], rows.shape[-1]
+    chunk = max(1, min(ny, (1 << 30) // (nx * 8)))
+    stage = torch.empty((chunk, nx), dtype=torch.float64).pin_memory()
+    scratch = torch.empty((chunk, nx), dtype=torch.float64, device=rows.device)
+    total = ny * nx * 8
+    secs = {}
+    for name in ("d2h", "h2d"):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a in range(0, ny, chunk):
+            m = min(chunk, ny - a)
+            if name == "d2h":
+                stage[:m].copy_(rows[a : a + m], non_blocking=True)
+            else:
+                scratch[:m].copy_(stage[:m], non_blocking=True)
+            torch.cuda.synchronize()
+        secs[name] = time.perf_counter() - t0
+    del stage, scratch
+    return {"what": "the owned rows of one finest-level array (b) device -> host and the same bytes host -> device, through a "
+                    "pinned staging buffer, chunks of at most 1 GiB",
+            "bytes": total, "d2h_ms": 1e3 * secs["d2h"], "h2d_ms": 1e3 * secs["h2d"],
+            "d2h_gbps": total / secs["d2h"] / 1e9, "h2d_gbps": total / secs["h2d"] / 1e9}
+
+
 def main():
     args = parse()
     # Libraries write to the process's standard output too (RCCL prints a version banner there when it makes its
@@ -214,12 +311,23 @@ def main():
     args.n_para = n_para
     h = 20.0 / 2 ** (n + 1)
 
+    # N > 1: what an exchange round and the all-gather cost here decides how many levels are cut into slabs
+    calib = None
+    if world > 1 and not args.no_comm_calibration and not args.dist_levels:
+        try:
+            calib = calibrate_comm(torch, dist, world, rank, gnx, 12 if not (args.no_fused or args.no_recompute) else 8)
+        except Exception as e:  # the cost model's defaults then decide (all ranks fail alike or the job ends)
+            calib = {"error": repr(e)}
+    t_round = calib["t_round_us"] * 1e-6 if calib and "t_round_us" in calib else None
+    gather_bw = calib["gather_gbps"] * 1e9 if calib and "gather_gbps" in calib else None
+
     def make_engine(tune):
         e = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, coarse_ordering=args.ordering,
                           use_graph=not args.no_graph, fused=not args.no_fused,
                           eager_dead_levels=not args.lazy_dead_levels, batch=args.batch or None,
                           recompute_presmoothing=not args.no_recompute, jacobi_omega=args.jacobi_omega,
-                          tune_placement=tune)
+                          tune_placement=tune, dist_levels=args.dist_levels or None, t_round=t_round, gather_bw=gather_bw,
+                          overlap_min_rows=args.overlap_min_rows)
         fill_rhs(e, torch, n, rank)
         torch.cuda.synchronize()
         return e
@@ -256,10 +364,24 @@ def main():
     errs += eng.cycles(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # ---- host time to issue one cycle: the same cycles again, the clock stopped before the device is waited for
+    barrier()
+    t0 = time.perf_counter()
+    eng.ops.begin()
+    for _ in range(args.steps):
+        eng._run_cycle()
+        eng._reduce_err()
+    host_issue_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+    eng._flush_pending()
+    eng.ops.end()
+    eng.materialize_residual()
+    barrier()
 
     # ---- dominant kernel, timed with HIP events on the stream it is launched on.
     # With fused passes that is the finest level's single smoothing pass of the cycle
@@ -323,6 +445,22 @@ def main():
     alg_bytes_launch = alg_bpp * pts_launch
     achieved = own_bytes_launch / (dom_ms * 1e-3) / 1e9
 
+    # ---- per-rank record, gathered to rank 0 (N > 1: what the first multi-GPU run needs to be read and re-tuned)
+    mine = {"rank": rank, "device": dev_index, "ms_per_step_local": 1e3 * dt_local / args.steps, "host_issue_ms_per_cycle": host_issue_ms,
+            "finest_pass_ms": dom_ms, "jacobi_sweep_ms": sweep_ms, "rounds_per_cycle": eng.rounds_per_cycle(),
+            "passes_cut": eng.split_passes, "comm_mode": getattr(eng.comm, "mode", None),
+            "placement_ms_chosen": (eng.placement or {}).get("ms_chosen_combination")}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    pcie = None
+    if rank == 0 and not args.no_pcie and not args.batch:
+        try:
+            pcie = pcie_copy(torch, eng)
+        except Exception as e:
+            pcie = {"error": repr(e)}
+
     if rank == 0:
         unknowns = (gny - 2) * (gnx - 2) * nprob
         ms = 1e3 * dt / args.steps
@@ -368,7 +506,16 @@ def main():
                                       "rounds_per_cycle": eng.rounds_per_cycle()} if world > 1 else None),
                 "dead_whole_domain_levels": "computed every cycle" if eng.eager_dead_levels else "on demand", "backend": args.backend if world > 1 else None,
                 "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                "comm": ({"mode": getattr(eng.comm, "mode", None), "calibration": calib,
+                          "note": "mode native = raw RCCL send/recv groups issued by libmg_hip.so on the engine's streams; "
+                                  "calibration = one exchange round and one all-gather timed before the engine was built, "
+                                  "which the choice of distributed_levels was made from (--dist-levels / MG_T_ROUND_US / "
+                                  "MG_GATHER_GBPS override)"} if world > 1 else None),
             },
+            "host_issue_ms_per_cycle": host_issue_ms,
+            "per_rank": per_rank,
+            # not part of `value` (the timed cycles run on arrays resident in HBM): what moving one array costs
+            "pcie": pcie,
             # the cycle on arrays as the allocator hands them out (no placement selection), 5 cycles on an engine of its own
             "untuned_ms_per_step": untuned_ms,
             "roofline": {

@@ -45,7 +45,7 @@ int main(int argc, char **argv)
             b[j * nx0 + i] = b_max * exp(-(X * X + Y * Y) * 4);
         }
     mg_solver *s;
-    CHECK(mg_solver_create(nx0, nx0, n_para, h, MG_SOLVER_TUNE_PLACEMENT, &s)); /* no other flag: the reference's schedule */
+    CHECK(mg_solver_create(nx0, nx0, n_para, h, 0, &s)); /* no flag: the reference's schedule */
     CHECK(mg_solver_upload(s, MG_SOLVER_B, b, nx0));
     for (int rep = 0; rep < 2; rep++) {
         int it;

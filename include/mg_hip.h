@@ -353,15 +353,18 @@ int mg_allreduce_max(mg_comm *c, uint64_t *words, int64_t count, void *stream);
  *                      MG_SOLVER_LAZY_DEAD_LEVELS   skip the whole-domain levels below the first,
  *                                                   which nothing reads under the reference's loop
  *                                                   bounds (ignored with FIX_COARSE_ASCENT)
- *                      MG_SOLVER_TUNE_PLACEMENT     create picks the finest level's arrays among up to 24
- *                                                   candidate allocations by how fast the finest pass runs
- *                                                   when it writes into each (grids of >= 1 GiB per array;
- *                                                   about half a second; results unchanged)
+ *                      MG_SOLVER_NO_PLACEMENT       on grids of >= 1 GiB per array create picks the finest
+ *                                                   level's arrays among up to 26 candidate allocations by
+ *                                                   how fast the finest pass runs when it writes into each
+ *                                                   (about half a second; results unchanged; the same launch
+ *                                                   is 10 % slower on some allocations than on others); this
+ *                                                   flag takes the arrays as the allocator hands them out
+ *                      MG_SOLVER_TUNE_PLACEMENT     accepted and ignored (the selection used to be opt-in)
  *   mg_solver_set      "jacobi_omega" (0 < w <= 1, 1 = the reference's sweep), "max_cycles"
  *                      (default 100, :270), "recompute_min_nx" / "recompute_min_blocks" (size from
  *                      which a coarse level recomputes its pre-smoothing instead of storing it)
- *   mg_solver_placement  number of candidate arrays create timed under MG_SOLVER_TUNE_PLACEMENT
- *                      (-1: placement was not tuned)
+ *   mg_solver_placement  number of candidate arrays the placement selection of create timed
+ *                      (-1: none -- a small grid, MG_SOLVER_NO_PLACEMENT, or memory was short)
  *   mg_solver_upload   finest-level b (MG_SOLVER_B) or x (MG_SOLVER_X: initial guess and Dirichlet
  *                      boundary values) from a host or device array of gny rows, src_ld apart
  *   mg_solver_solve    solve() (:232-348): one sweep + residual, then V-cycles until max|r| <= eps,
@@ -381,6 +384,7 @@ typedef struct mg_solver mg_solver;
 #define MG_SOLVER_NO_GRAPH 4
 #define MG_SOLVER_LAZY_DEAD_LEVELS 8
 #define MG_SOLVER_TUNE_PLACEMENT 16
+#define MG_SOLVER_NO_PLACEMENT 32
 enum { MG_SOLVER_X = 0, MG_SOLVER_B = 1, MG_SOLVER_R = 2, MG_SOLVER_XW = 3, MG_SOLVER_BW = 4, MG_SOLVER_RW = 5 };
 int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0, int flags, mg_solver **out);
 int mg_solver_destroy(mg_solver *s);

@@ -82,7 +82,7 @@ SIGNATURES = {
     "mg_solver_solve": ([_p, _d, C.POINTER(_n), C.POINTER(_d)], _n),
     "mg_solver_history": ([_p, C.POINTER(_d), _n, C.POINTER(_n), C.POINTER(_n)], _n),
 }
-SOLVER_FIX_COARSE_ASCENT, SOLVER_REDBLACK, SOLVER_NO_GRAPH, SOLVER_LAZY_DEAD_LEVELS, SOLVER_TUNE_PLACEMENT = 1, 2, 4, 8, 16
+SOLVER_FIX_COARSE_ASCENT, SOLVER_REDBLACK, SOLVER_NO_GRAPH, SOLVER_LAZY_DEAD_LEVELS, SOLVER_TUNE_PLACEMENT, SOLVER_NO_PLACEMENT = 1, 2, 4, 8, 16, 32
 SOLVER_ARRAYS = {"x": 0, "b": 1, "r": 2, "xw": 3, "bw": 4, "rw": 5}
 
 

@@ -61,7 +61,7 @@ struct mg_solver {
     bool r_stale;  // the finest residual array is older than x
     int it;
     bool diverged;
-    int placement_candidates; // candidate arrays timed by MG_SOLVER_TUNE_PLACEMENT, -1: placement not tuned
+    int placement_candidates; // candidate arrays timed by the placement selection, -1: placement not tuned
     std::vector<double> hist;
 };
 
@@ -294,7 +294,7 @@ int collect_err(mg_solver *s, int a, double *err)
 // combination of the two written allocations, fixed when they are made and not predictable from user space (in a
 // fresh process the first eleven 8-GiB allocations are slow as x beside a coarse right-hand side allocated before
 // them, all later ones fast; a coarse right-hand side allocated after the fast ones makes the pass slow again).
-// With MG_SOLVER_TUNE_PLACEMENT create measures: the coarse right-hand side is allocated first AND KEPT (*cb_out:
+// Unless MG_SOLVER_NO_PLACEMENT is given create therefore measures: the coarse right-hand side is allocated first AND KEPT (*cb_out:
 // it becomes the next level's b), candidates of the finest array's size are allocated one by one, each is timed
 // as the output of the cycle's finest pass, and as soon as both kinds have been seen and four candidates are of
 // the fast kind those become fin[] = {xa, xb, b, r}, in the assignment whose pass is fastest; all zero.
@@ -522,7 +522,7 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
                "mg_solver_create: the first whole-domain level needs at least 2 cells per side");
     MG_REQUIRE(h0 > 0, "mg_solver_create: mesh width must be positive");
     MG_REQUIRE((flags & ~(MG_SOLVER_FIX_COARSE_ASCENT | MG_SOLVER_REDBLACK | MG_SOLVER_NO_GRAPH | MG_SOLVER_LAZY_DEAD_LEVELS |
-                          MG_SOLVER_TUNE_PLACEMENT)) == 0,
+                          MG_SOLVER_TUNE_PLACEMENT | MG_SOLVER_NO_PLACEMENT)) == 0,
                "mg_solver_create: unknown flag bits in %d", flags);
     mg_solver *s = new (std::nothrow) mg_solver();
     MG_REQUIRE(s, "mg_solver_create: out of host memory");
@@ -558,7 +558,7 @@ extern "C" int mg_solver_create(int64_t gny, int64_t gnx, int n_para, double h0,
         bool ok = true;
         double *fin[4] = {nullptr, nullptr, nullptr, nullptr};
         double *cb1 = nullptr, *xa1 = nullptr; // what the finest pass restricts into and level 1's x, when the placement selection made them
-        if (flags & MG_SOLVER_TUNE_PLACEMENT) {
+        if (!(flags & MG_SOLVER_NO_PLACEMENT)) { // returns at once for grids below 1 GiB per array
             place_finest(s, fin, &cb1, &xa1);
             for (int k = 0; k < 4; ++k)
                 if (fin[k]) s->allocs.push_back(fin[k]);

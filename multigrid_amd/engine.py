@@ -48,7 +48,7 @@ class SlabMultigrid:
                  coarse_ordering="lexicographic", fix_coarse_ascent=False, keep_ascent_residuals=False,
                  max_cycles=100, use_graph=True, fused=True, halo=None, eager_dead_levels=False,
                  store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
-                 recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=False,
+                 recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=None,
                  overlap_min_rows=4096, batch_stop="max", fine_smoother="jacobi", comm=None,
                  recompute_last_distributed=True, dist_levels=None, t_round=None, gather_bw=None):
         if ops is None:
@@ -158,6 +158,11 @@ class SlabMultigrid:
         fin = None
         self.placement_seconds = 0.0
         t0 = time.perf_counter()
+        # tune_placement: None = wherever it matters and is safe -- finest arrays of at least 1 GiB (_place_finest returns
+        # at once below that) on a GPU this rank has to itself (ranks that share one GPU over gloo, as the rehearsal
+        # tests do, would take each other's memory with their candidate arrays); True / "verbose" / False = the caller's word
+        if tune_placement is None:
+            tune_placement = world == 1 or not getattr(self.comm, "staged", False)
         if tune_placement and batch is None and getattr(ops, "supports_placement", False) and self.fused:
             fin = self._place_finest(verbose=tune_placement == "verbose")
         cb1 = xa1 = None  # the array the finest pass restricts into and level 1's x, if the placement selection made them

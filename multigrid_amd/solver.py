@@ -16,12 +16,12 @@ from ._lib import MgError, check
 class NativeSolver:
     def __init__(self, gny, gnx, n_para, h0, *, fix_coarse_ascent=False, coarse_ordering="lexicographic", use_graph=True,
                  eager_dead_levels=True, jacobi_omega=1.0, max_cycles=100, recompute_min_nx=None, recompute_min_blocks=None,
-                 tune_placement=False):
+                 tune_placement=True):
         self.L = _lib.lib()
         flags = (_lib.SOLVER_FIX_COARSE_ASCENT if fix_coarse_ascent else 0) | \
                 (_lib.SOLVER_REDBLACK if coarse_ordering == "redblack" else 0) | \
                 (0 if use_graph else _lib.SOLVER_NO_GRAPH) | (0 if eager_dead_levels else _lib.SOLVER_LAZY_DEAD_LEVELS) | \
-                (_lib.SOLVER_TUNE_PLACEMENT if tune_placement else 0)
+                (0 if tune_placement else _lib.SOLVER_NO_PLACEMENT)
         h = C.c_void_p()
         check(self.L.mg_solver_create(gny, gnx, n_para, h0, flags, C.byref(h)))
         self._h = h
@@ -38,7 +38,8 @@ class NativeSolver:
 
     @property
     def placement_candidates(self):
-        """Number of candidate arrays tune_placement timed to pick the finest x arrays; None: placement not tuned."""
+        """Number of candidate arrays create timed to pick the finest level's arrays (grids of at least 1 GiB per array,
+        unless tune_placement=False); None: placement not tuned."""
         g = C.c_int()
         check(self.L.mg_solver_placement(self._h, C.byref(g)))
         return None if g.value < 0 else g.value

@@ -21,7 +21,7 @@ def test_bench_runs_under_torch_distributed_run():
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--exp", "10", "--backend", backend, "--no-cpu-baseline", "--roofline-iters", "2"]
+           "--exp", "10", "--backend", backend, "--no-cpu-baseline", "--roofline-iters", "2", "--overlap-min-rows", "512"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -33,6 +33,31 @@ def test_bench_runs_under_torch_distributed_run():
     assert d["config"]["exchange_overlap"]["rounds_per_cycle"] >= 2
     assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and 0 < d["cycle"]["frac_of_peak"] < 1
     assert d["metric"] == "unknowns*V-cycles/s" and d["unit"] == "unknowns*V-cycles/s"
+    # what a first multi-GPU run is read and re-tuned from: the exchange round and the all-gather timed at start-up (the
+    # distribution depth was chosen from them), and every rank's own record
+    cal = d["config"]["comm"]["calibration"]
+    assert cal["t_round_us"] > 0 and cal["gather_gbps"] > 0 and cal["round_gpu_us"] > 0 and cal["allgather_gpu_us"] > 0
+    assert d["config"]["comm"]["mode"] == ("native" if backend == "nccl" else "staged") == cal["comm_mode"]
+    assert d["config"]["exchange_overlap"]["min_rows_per_rank"] == 512 and d["config"]["exchange_overlap"]["passes_cut"] > 0
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    for r in d["per_rank"]:
+        assert r["host_issue_ms_per_cycle"] > 0 and r["finest_pass_ms"] > 0 and r["ms_per_step_local"] > 0
+        assert r["rounds_per_cycle"] == d["config"]["exchange_overlap"]["rounds_per_cycle"] and r["passes_cut"] > 0
+    assert d["host_issue_ms_per_cycle"] > 0
+    assert d["pcie"]["bytes"] == 2049 * 2049 * 8 and d["pcie"]["h2d_gbps"] > 0 and d["pcie"]["d2h_gbps"] > 0
+
+
+def test_bench_takes_the_distribution_depth_from_the_command_line():
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--exp", "9", "--backend", backend, "--no-cpu-baseline", "--roofline-iters", "2", "--dist-levels", "2", "--no-pcie"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["distributed_levels"] == 2 and d["config"]["comm"]["calibration"] is None and d["pcie"] is None
 
 
 def test_bench_refuses_several_gpus_without_a_launcher():

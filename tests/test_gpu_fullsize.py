@@ -67,6 +67,18 @@ def test_fused_graph_equals_separate_kernels_at_32769():
     b.close()
 
 
+def test_default_engine_selects_its_placement_at_32769():
+    """A caller who passes no switch gets the placement selection wherever the finest arrays are large enough for it to
+    matter (>= 1 GiB each): the finest pass on the chosen arrays is of the fast kind, and set-up stays short."""
+    e = _engine(14, 10, eager_dead_levels=True)
+    assert e.placement is not None and e.placement["candidates"] >= 4 and e.placement_seconds < 10
+    assert e.placement["ms_chosen_combination"] <= 1.03 * min(e.placement["ms_as_output"])
+    e.close()
+    small = _engine(10, 6)
+    assert small.placement is None
+    small.close()
+
+
 def test_power_of_two_scaling_is_exact_at_32769():
     import torch
     n, n_para = 14, 8

@@ -169,8 +169,9 @@ def test_c_program_runs_the_reference_script():
 
 
 def test_tuned_placement_changes_nothing_but_where_the_arrays_lie():
-    """MG_SOLVER_TUNE_PLACEMENT: create times candidate allocations as the output of the finest pass (grids of at
-    least 1 GiB per array) and keeps the fastest as the x arrays, zeroed; everything computed afterwards is the same."""
+    """Placement selection (the default; MG_SOLVER_NO_PLACEMENT switches it off): create times candidate allocations as
+    the output of the finest pass (grids of at least 1 GiB per array) and keeps the fastest as the x arrays, zeroed;
+    everything computed afterwards is the same."""
     from multigrid_amd.solver import NativeSolver
     gny, gnx, n_para = 16385, 8193, 8
     b = _rhs(gny, gnx, 2)

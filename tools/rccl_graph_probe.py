@@ -4,7 +4,9 @@
 all-gather and the MAX-reduction are captured on the engine's stream with the library's own capture calls, replayed,
 and compared with the eager sequence; host time per eager round against GPU time per captured round.
 
-    python tools/rccl_graph_probe.py [p2p,gather,reduce]     (which of the three to put into the graph; default all)
+    python tools/rccl_graph_probe.py [p2p,gather,reduce] [--native]
+        which of the three to put into the graph (default all); --native: the calls are the raw RCCL calls libmg_hip.so
+        makes on the engine's stream (mg_halo_exchange, mg_allgather_rows, mg_allreduce_max) instead of torch.distributed's
 """
 import os
 import socket
@@ -32,6 +34,13 @@ def main():
     from multigrid_amd.ops import HipOps
     ops = HipOps(torch.device("cuda", 0))
     comm = SlabComm(ops, None, 1, 0)
+    native = "--native" in sys.argv
+    if native:
+        from multigrid_amd.comm import torch_nccl_comm
+        comm.allreduce_max(ops.zeros(1, 1).view(-1))  # the communicator exists once it has carried a collective
+        comm._attach(torch_nccl_comm(None, ops.device))
+        assert comm.mode == "native"
+    print("communication calls:", comm.mode if native else "torch.distributed", flush=True)
     H, rows, ld = 12, 4096, 32784
     ops.begin()
     with ops.ctx():
@@ -44,7 +53,8 @@ def main():
     recvs = [(x[rows + H:].view(-1), 0), (x[:H].view(-1), 0)]
     batch = comm.prepare(sends, recvs)
 
-    which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["p2p", "gather", "reduce"]
+    plain = [a for a in sys.argv[1:] if not a.startswith("--")]
+    which = plain[0].split(",") if plain else ["p2p", "gather", "reduce"]
 
     def sequence():
         with ops.ctx():
