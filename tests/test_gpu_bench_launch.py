@@ -44,7 +44,7 @@ def test_bench_runs_under_torch_distributed_run():
         assert r["host_issue_ms_per_cycle"] > 0 and r["finest_pass_ms"] > 0 and r["ms_per_step_local"] > 0
         assert r["rounds_per_cycle"] == d["config"]["exchange_overlap"]["rounds_per_cycle"] and r["passes_cut"] > 0
     assert d["host_issue_ms_per_cycle"] > 0
-    assert d["pcie"]["bytes"] == 2049 * 2049 * 8 and d["pcie"]["h2d_gbps"] > 0 and d["pcie"]["d2h_gbps"] > 0
+    assert d["pcie"]["bytes"] == 2048 * 2049 * 8 and d["pcie"]["h2d_gbps"] > 0 and d["pcie"]["d2h_gbps"] > 0
 
 
 def test_bench_takes_the_distribution_depth_from_the_command_line():
