@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--overlap-min-rows", type=int, default=4096,
                     help="N > 1: passes of levels with at least this many rows per rank are cut into interior rows and slab ends "
                          "around their halo exchange")
+    ap.add_argument("--graph-comm", action="store_true",
+                    help="N > 1: the whole V-cycle of a rank, halo exchanges and all-gather included (raw RCCL calls recorded by "
+                         "hipGraph capture), is one graph launch per cycle instead of one launch per pass and exchange")
     ap.add_argument("--no-comm-calibration", action="store_true",
                     help="N > 1: do not time an exchange round and an all-gather at start-up; the cost model's defaults decide")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host <-> device copy of one finest-level array")
@@ -327,7 +330,7 @@ def main():
                           eager_dead_levels=not args.lazy_dead_levels, batch=args.batch or None,
                           recompute_presmoothing=not args.no_recompute, jacobi_omega=args.jacobi_omega,
                           tune_placement=tune, dist_levels=args.dist_levels or None, t_round=t_round, gather_bw=gather_bw,
-                          overlap_min_rows=args.overlap_min_rows)
+                          overlap_min_rows=args.overlap_min_rows, graph_comm=args.graph_comm)
         fill_rhs(e, torch, n, rank)
         torch.cuda.synchronize()
         return e
@@ -506,7 +509,7 @@ def main():
                                       "rounds_per_cycle": eng.rounds_per_cycle()} if world > 1 else None),
                 "dead_whole_domain_levels": "computed every cycle" if eng.eager_dead_levels else "on demand", "backend": args.backend if world > 1 else None,
                 "ranks_seen": dist.get_world_size() if world > 1 else 1,
-                "comm": ({"mode": getattr(eng.comm, "mode", None), "calibration": calib,
+                "comm": ({"mode": getattr(eng.comm, "mode", None), "calibration": calib, "cycle_is_one_graph": bool(eng.graph_comm),
                           "note": "mode native = raw RCCL send/recv groups issued by libmg_hip.so on the engine's streams; "
                                   "calibration = one exchange round and one all-gather timed before the engine was built, "
                                   "which the choice of distributed_levels was made from (--dist-levels / MG_T_ROUND_US / "

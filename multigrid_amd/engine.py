@@ -50,7 +50,7 @@ class SlabMultigrid:
                  store_residual_every_cycle=False, batch=None, dist_min_rows=None, recompute_presmoothing=True,
                  recompute_min_nx=1024, recompute_min_blocks=1024, jacobi_omega=1.0, tune_placement=None,
                  overlap_min_rows=4096, batch_stop="max", fine_smoother="jacobi", comm=None,
-                 recompute_last_distributed=True, dist_levels=None, t_round=None, gather_bw=None):
+                 recompute_last_distributed=True, dist_levels=None, t_round=None, gather_bw=None, graph_comm=False):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()
@@ -128,6 +128,13 @@ class SlabMultigrid:
         # are not computed every cycle but on demand (sync_whole_levels), with identical values.
         self.eager_dead_levels = eager_dead_levels or fix_coarse_ascent
         self.use_graph = use_graph and getattr(ops, "supports_graphs", False)
+        # One graph per cycle: always on one rank.  On several ranks the distributed levels are launched one by one
+        # with the exchanges between them, unless graph_comm is set and the exchanges are the library's raw RCCL calls
+        # (comm.mode == "native"), which hipGraph capture records like kernels: the whole cycle, exchanges and the
+        # all-gather included, is then one graph launch per rank (the MAX-reduction of the norm stays outside).
+        # Every rank must make the same choice.
+        self.graph_comm = bool(graph_comm) and world > 1 and self.use_graph and getattr(self.comm, "mode", None) == "native"
+        self._whole_graph = self.use_graph and (world == 1 or self.graph_comm)
         self.it = 0
         self.err_history = []
         self.diverged = False
@@ -806,7 +813,7 @@ class SlabMultigrid:
             return
         o = self.ops
         with o.side(after):
-            if self.use_graph and self.world > 1:  # on one rank they are part of the cycle graph
+            if self.use_graph and not self._whole_graph:  # else they are part of the cycle graph
                 if self._dead_graph is None:
                     with o.capture() as cap:
                         self._tail_below()
@@ -855,7 +862,7 @@ class SlabMultigrid:
     def _run_middle(self):
         # a from-zero pass always writes _xa[l] and an even number of passes follows on the ascent, so
         # the result lands in the same array every cycle: one captured graph serves all cycles
-        if not self.use_graph or self.world == 1:  # on one rank the middle is part of the cycle graph
+        if not self.use_graph or self._whole_graph:  # the middle is part of the cycle graph
             self._mid_result = self._middle()
         else:
             if self._mid_graph is None:
@@ -866,9 +873,10 @@ class SlabMultigrid:
         # On one rank the side work is enqueued after the rest of the cycle (see _cycle), from this point of
         # the main sequence: captured in that order the graph runs the ascent first and the dead levels beside
         # it; captured right here, the ascent waited for most of them (0.26 ms per cycle at 32769 x 32769).
-        if self.world == 1:
+        if self.world == 1 or self._whole_graph:
             self._dead_mark = self.ops.mark() if self._has_dead_levels() else None
         else:
+            self._dead_mark = None
             self._dead_levels()
         return self._mid_result
 
@@ -892,15 +900,19 @@ class SlabMultigrid:
         if k == 1:
             corr = self._window(corr, 1)
         self._smooth_level0(self.N2, want_norm=True, crs=corr, store_r=store_r)
-        if self.world == 1 and self._dead_mark is not None:
+        if self._dead_mark is not None:
             self._dead_levels(after=self._dead_mark)
         self.ops.join_side()
+        if self.graph_comm:
+            # a captured cycle is the same every time it is replayed: the halo of the right-hand side the finest pass
+            # has just restricted is exchanged here instead of being left to the next cycle's first pass
+            self._flush_pending()
 
     # ------------------------------------------------------------------ drivers
     def _run_cycle(self, store_r=False):
         self._last_parity = self._cur0  # selects the norm accumulator this cycle fills
         store_r = bool(store_r) and self.fused and not self.store_residual_every_cycle
-        if self.use_graph and self.world == 1:
+        if self._whole_graph:
             # one graph per array the finest x starts the cycle in (a cycle may leave it in the other)
             # and per residual-store variant
             key = (self._cur0, store_r)

@@ -12,6 +12,8 @@ the HIP kernels of libmg_hip.so.  Two classes:
                      the reference's own schedule, halo-exchange order and stop rule
                      (parallel_multigrid.py:100-114, :117-138, :232-348).  Per-cycle errors,
                      iteration counts and the returned arrays equal the reference's bit for bit.
+                     A per-rank driver written for mpiexec runs unchanged under
+                     ``multigrid_amd.spmd.run`` (one thread per rank, ``spmd.MPI.COMM_WORLD``).
 ``GlobalMultigrid``  the same V-cycle on the undecomposed grid, backed by the row-slab engine
                      (multigrid_amd.engine): the fast path, 1..N GPUs.
 
@@ -317,6 +319,13 @@ class Multigrid:
             raise MgError("b0, x0 and r0 must be square arrays of one shape")
         self.b0, self.x0, self.r0 = b0, x0, r0
         self.h0, self.epsilon = h0, epsilon
+        # inside multigrid_amd.spmd.run (one thread per rank) the calling thread's rank and the run's world are the
+        # defaults, so that the reference's constructor call needs no extra keyword
+        from . import spmd
+        ctx = spmd.current()
+        if ctx is not None:
+            rank = ctx[1] if rank is None else rank
+            world = ctx[0].world if world is None else world
         self.rank = _current_rank if rank is None else rank
         if self.rank not in (0, 1, 2, 3):
             raise ValueError("rank must be 0..3")
@@ -337,6 +346,12 @@ class Multigrid:
     def solve(self):
         """Solve by repeating V-cycles; returns this rank's max|r| (halo lines included), as the
         reference does (:336, :348).  Collective over the four ranks of the world."""
+        from . import spmd
+        ctx = spmd.current()
+        if ctx is not None and ctx[0].world is self.world and ctx[1] == self.rank:
+            # the four ranks are four threads that call solve() together, as under mpiexec: rank 0's thread runs the
+            # collective solve once all have arrived, every rank returns its own error
+            return ctx[0].on_rank0(self.world.solve_all)[self.rank]
         return self.world._solve_for(self.rank)
 
 
@@ -345,6 +360,14 @@ def gather_blocks(comm, M_block, M_full):
     (core/parallel_multigrid.py:117-138).  ``M_block`` is either a sequence of the four ranks' blocks
     or one rank's level-0 array (x0, b0 or r0 of a ``Multigrid`` registered in ``comm``), in which
     case the other ranks' corresponding arrays are looked up in the world ``comm``."""
+    from . import spmd
+    if isinstance(comm, spmd.ThreadComm) and not isinstance(M_block, (list, tuple)):
+        # every rank passes its own block and gets the whole array, as after the reference's four broadcasts
+        blocks = comm.allgather(M_block)
+        with comm.gpu_lock:
+            gather_blocks(None, blocks, M_full)
+        comm.Barrier()  # nobody changes its block while another rank still copies from it
+        return
     if isinstance(M_block, (list, tuple)):
         blocks = list(M_block)
     else:

@@ -162,3 +162,76 @@ def test_module_main_reproduces_the_reference_script(name, tmp_path, capsys):
     out = capsys.readouterr().out
     assert out.count("v cycles") == 2 and f"nx = {2 ** int(g['n']) + 1}" in out
     assert np.isfinite(a_full).all() and np.abs(R_full).max() > 0
+
+
+def _reference_style_driver(n, n_para, eps, nsolves, record):
+    """A per-rank program written the way the reference's test driver is (test/test.py:33-87): every rank asks the
+    communicator who it is, splits the global right-hand side, builds ONE Multigrid without any extra keyword, mutates
+    its right-hand side and solves ten times over, reduces the error to rank 0, gathers the solution."""
+    from multigrid_amd.parallel_multigrid import Multigrid, gather_blocks, residual, split
+    from multigrid_amd.spmd import MPI
+    comm = MPI.COMM_WORLD
+    rank = comm.Get_rank()
+    b0, h = vortex_rhs(n)
+    nx1 = 2 ** n + 1
+    b = np.zeros((nx1 + 1, nx1 + 1))
+    split(b0, b, rank)
+    a = np.zeros_like(b)
+    R = np.zeros_like(b)
+    poisson = Multigrid(b, a, R, h, eps, n, n_para)
+    errs, its = [], []
+    for _ in range(nsolves):
+        b[1:-1] += b[0:-2]
+        b /= 2
+        err = poisson.solve()
+        errs.append(err)
+        its.append(poisson.it)
+    worst = comm.reduce(errs[-1], MPI.MAX, 0)
+    votes = comm.allreduce(1)
+    a_full = np.zeros_like(b0)
+    gather_blocks(comm, a, a_full)
+    record[rank] = (errs, its, a, R, a_full, worst, votes, comm.Get_size(), poisson.n, poisson.n_para)
+    return rank
+
+
+def test_unchanged_per_rank_driver_runs_under_spmd_run():
+    """The reference's calling pattern as it stands -- one Multigrid(b, a, R, h, eps, n, n_para) per rank, no rank= or
+    world= keyword, COMM_WORLD-style reduce / allreduce, gather_blocks(comm, block, full) -- on four threads; the
+    reference's own size (n = 8, n_para = 4), its recorded four-rank run as the expectation."""
+    from multigrid_amd import spmd
+    g = np.load(os.path.join(GOLDEN, "solve_t_n8_p4.npz"))
+    n, n_para, nsolves = int(g["n"]), int(g["n_para"]), int(g["nsolves"])
+    assert int(g["mutate"]) == 1 and str(g["rhs"]) == "test"
+    record = {}
+    world_out = spmd.run(_reference_style_driver, n, n_para, float(g["eps"]), nsolves, record)
+    assert world_out == [0, 1, 2, 3]
+    for rank in range(4):
+        errs, its, a, R, a_full, worst, votes, size, pn, pp = record[rank]
+        assert errs == g["errs"][rank].tolist() and its == g["its"][rank].tolist()
+        assert np.array_equal(a[::8, ::8], g[f"x{rank}_s8"]) and np.array_equal(R[::8, ::8], g[f"r{rank}_s8"])
+        assert float(np.sum(a)) == float(g[f"x{rank}_sum"])
+        assert worst == (g["errs"][:, -1].max() if rank == 0 else None)
+        assert votes == 4 and size == 4 and (pn, pp) == (n, n_para)
+    # every rank holds the same gathered array, stitched as the reference stitches it
+    nx2 = 2 ** n + 1
+    full = record[0][4]
+    a = [record[k][2] for k in range(4)]
+    assert np.array_equal(full[:nx2, :nx2], a[0][:-1, :-1]) and np.array_equal(full[nx2:, nx2:], a[3][2:, 2:])
+    assert np.array_equal(full[:nx2, nx2:], a[1][:-1, 2:]) and np.array_equal(full[nx2:, :nx2], a[2][2:, :-1])
+    for rank in range(1, 4):
+        assert np.array_equal(record[rank][4], full)
+
+
+def test_spmd_run_hands_a_rank_error_to_the_caller():
+    from multigrid_amd import spmd
+
+    def driver():
+        comm = spmd.MPI.COMM_WORLD
+        if comm.Get_rank() == 2:
+            raise ValueError("rank 2 gives up")
+        comm.Barrier()
+
+    with pytest.raises(ValueError, match="rank 2 gives up"):
+        spmd.run(driver)
+    with pytest.raises(RuntimeError):
+        spmd.MPI.COMM_WORLD

@@ -161,7 +161,25 @@ def _worker(port, q):
             engine_runs.append((len(errs), bool(np.isfinite(errs).all()), per_cycle, eng.rounds_per_cycle(), eng.split_passes > 0,
                                 1 <= eng.it <= 3, eng.n_dist >= 2))
             eng.close()
-        print("loopback engine runs:", engine_runs, flush=True)
+        # the same rank with its whole cycle, exchanges included, captured into one hipGraph per cycle (graph_comm):
+        # the raw RCCL calls are recorded like kernels; values equal the launch-by-launch run bit for bit
+        pair = []
+        for gc in (False, True):
+            ops3 = HipOps(torch.device("cuda", 0))
+            lc = LoopbackComm(ops3, 8, 3, rccl=True, native=True)
+            eng = SlabMultigrid(8 * 1024 + 1, 1025, 6, 0.01, 0.0, ops=ops3, world=8, rank=3, comm=lc, eager_dead_levels=True,
+                                overlap_min_rows=1, dist_min_rows=64, graph_comm=gc)
+            assert eng.graph_comm == gc
+            a, e = eng.owned_rows()
+            eng.set_b_rows(torch.from_numpy(np.random.default_rng(7).standard_normal((e - a, 1025))).cuda())
+            eng.presmooth()
+            errs = eng.cycles(2)
+            errs += eng.cycles(3)
+            pair.append((errs, eng.local_rows(eng.x0).cpu().numpy(), eng.local_rows(eng.r0).cpu().numpy()))
+            eng.close()
+        graph_comm_ok = pair[0][0] == pair[1][0] and np.array_equal(pair[0][1], pair[1][1]) and np.array_equal(pair[0][2], pair[1][2])
+        print("loopback engine runs:", engine_runs, "whole-cycle graph with exchanges equals eager:", graph_comm_ok, flush=True)
+        graphs_ok = graphs_ok and graph_comm_ok
         graphs_ok = graphs_ok and all(r[0] == 3 and r[1] and r[2] == r[3] and r[4] and r[5] and r[6] for r in engine_runs)
         ncomm.close()
         q.put((ok_direct + (graphs_ok,), ok_native, per_round, per_round_native))
