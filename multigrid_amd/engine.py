@@ -131,7 +131,8 @@ class SlabMultigrid:
         # One graph per cycle: always on one rank.  On several ranks the distributed levels are launched one by one
         # with the exchanges between them, unless graph_comm is set and the exchanges are the library's raw RCCL calls
         # (comm.mode == "native"), which hipGraph capture records like kernels: the whole cycle, exchanges and the
-        # all-gather included, is then one graph launch per rank (the MAX-reduction of the norm stays outside).
+        # all-gather included, is then one graph launch per rank (the MAX-reduction of the norm stays outside), with
+        # every exchange on the cycle's main stream: passes are not cut around their exchanges in this mode.
         # Every rank must make the same choice.
         self.graph_comm = bool(graph_comm) and world > 1 and self.use_graph and getattr(self.comm, "mode", None) == "native"
         self._whole_graph = self.use_graph and (world == 1 or self.graph_comm)
@@ -211,7 +212,10 @@ class SlabMultigrid:
         # arrived.  Done on levels with at least overlap_min_rows rows per rank (None: never); on smaller ones
         # the interior rows are too short-lived to hide an exchange behind (measured: 4096 and 2048 run alike,
         # 1024 and below slower).
-        self.overlap_min_rows = overlap_min_rows if (world > 1 and self.fused and hasattr(ops, "comm_side")) else None
+        # (not with graph_comm: RCCL calls are recorded correctly on the capturing stream itself, but a send/receive group
+        # issued on a stream that joined the capture through an event -- the communication stream of a cut pass -- ends
+        # the process inside the capture on RCCL 2.26 / HIP 7.0, tools/rccl_graph_probe2.py)
+        self.overlap_min_rows = overlap_min_rows if (world > 1 and self.fused and hasattr(ops, "comm_side") and not self.graph_comm) else None
         self.split_passes = 0  # passes cut this way so far (diagnostics)
         self._pending = None  # (level, exchange items) of a right-hand side whose halo is still to be filled
         self._graphs = {}

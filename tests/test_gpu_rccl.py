@@ -169,7 +169,7 @@ def _worker(port, q):
             lc = LoopbackComm(ops3, 8, 3, rccl=True, native=True)
             eng = SlabMultigrid(8 * 1024 + 1, 1025, 6, 0.01, 0.0, ops=ops3, world=8, rank=3, comm=lc, eager_dead_levels=True,
                                 overlap_min_rows=1, dist_min_rows=64, graph_comm=gc)
-            assert eng.graph_comm == gc
+            assert eng.graph_comm == gc and (eng.overlap_min_rows is None) == gc
             a, e = eng.owned_rows()
             eng.set_b_rows(torch.from_numpy(np.random.default_rng(7).standard_normal((e - a, 1025))).cuda())
             eng.presmooth()
