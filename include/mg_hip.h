@@ -398,6 +398,49 @@ int mg_solver_cycles(mg_solver *s, int k, double *errs);
 int mg_solver_solve(mg_solver *s, double eps, int *it_out, double *err_out);
 int mg_solver_history(mg_solver *s, double *errs, int capacity, int *count, int *diverged);
 
+/*
+ * The same solver on SEVERAL GPUs, one process (rank) per GPU: Multigrid.__init__ / Multigrid.solve of
+ * core/parallel_multigrid.py:153-348 with the reference's four block ranks (:49-56) replaced by `world` row slabs of
+ * the global (gny x gnx) grid.  Rank r owns global rows [r R, (r+1) R), R = (gny-1)/world (the last rank also the bottom
+ * boundary row) and keeps 12 halo rows above and below them.  The finest `n_dist` Jacobi levels are cut into slabs
+ * (dist_levels, or 0 = a cost model's choice; rows per rank must be divisible by 2^n_dist and the coarsest slab at
+ * least 12 rows tall); per cycle a rank issues one prepared RCCL send/receive group per fused pass of a distributed
+ * level (mg_halo_exchange; the reference exchanges after every sweep, :83-97,:108-111), one all-gather of the first
+ * replicated level's right-hand side (gather_blocks, :117-138) -- from there on every rank computes alike, as the
+ * reference replicates its whole-domain levels -- and one MAX-reduction of the norm (:342-345).  Every call of a
+ * cycle is issued on one stream, so a rank's whole cycle, communication included, is one hipGraph launch.  Results equal
+ * mg_solver_* on one GPU, and the reference's schedule on the undecomposed grid, bit for bit, for every `world`.
+ *
+ *   mg_dist_create     collective: every rank calls it with the same grid, flags and dist_levels, its own rank, and a
+ *                      communicator of `world` ranks in which it has that rank (mg_comm_attach / mg_comm_init; NULL
+ *                      for world = 1).  flags: MG_SOLVER_FIX_COARSE_ASCENT, _REDBLACK, _NO_GRAPH, _LAZY_DEAD_LEVELS as
+ *                      for mg_solver_create, and MG_DIST_LOOPBACK: a rehearsal of ONE rank of `world` alone, on a
+ *                      one-rank communicator with the rank as its own neighbours (values are meaningless then; the
+ *                      calls, their sizes and their cost are the real job's).
+ *   mg_dist_upload / mg_dist_download   the rank's OWNED rows of the finest-level b or x (download: also r), a host or
+ *                      device array of owned rows x gnx (mg_dist_info tells how many rows and where they start);
+ *                      downloading r is collective (one halo row of x is exchanged to bring r up to date).
+ *   mg_dist_presmooth / mg_dist_cycles / mg_dist_solve / mg_dist_history / mg_dist_set   as their mg_solver_*
+ *                      namesakes; collective; errs and the returned error are max|r| over ALL ranks.
+ *   mg_dist_info       the number of distributed levels (0 on one rank), the global row of the first owned row, the
+ *                      number of owned rows, and the communication rounds (exchanges and all-gathers) issued so far.
+ * All calls of one handle come from one thread, with the device it was created on current, in the same order on
+ * every rank.
+ */
+typedef struct mg_dist_solver mg_dist_solver;
+#define MG_DIST_LOOPBACK 64
+int mg_dist_create(int64_t gny, int64_t gnx, int n_para, double h0, int flags, mg_comm *comm, int rank, int world,
+                   int dist_levels, mg_dist_solver **out);
+int mg_dist_destroy(mg_dist_solver *s);
+int mg_dist_set(mg_dist_solver *s, const char *key, double value);
+int mg_dist_info(mg_dist_solver *s, int *n_dist, int64_t *first_global_row, int64_t *owned_rows, int64_t *rounds);
+int mg_dist_upload(mg_dist_solver *s, int which, const double *src, int64_t src_ld);
+int mg_dist_download(mg_dist_solver *s, int which, double *dst, int64_t dst_ld);
+int mg_dist_presmooth(mg_dist_solver *s);
+int mg_dist_cycles(mg_dist_solver *s, int k, double *errs);
+int mg_dist_solve(mg_dist_solver *s, double eps, int *it_out, double *err_out);
+int mg_dist_history(mg_dist_solver *s, double *errs, int capacity, int *count, int *diverged);
+
 #ifdef __cplusplus
 }
 #endif

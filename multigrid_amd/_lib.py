@@ -81,7 +81,18 @@ SIGNATURES = {
     "mg_solver_cycles": ([_p, _n, C.POINTER(_d)], _n),
     "mg_solver_solve": ([_p, _d, C.POINTER(_n), C.POINTER(_d)], _n),
     "mg_solver_history": ([_p, C.POINTER(_d), _n, C.POINTER(_n), C.POINTER(_n)], _n),
+    "mg_dist_create": ([_i, _i, _n, _d, _n, _p, _n, _n, _n, C.POINTER(_p)], _n),
+    "mg_dist_destroy": ([_p], _n),
+    "mg_dist_set": ([_p, C.c_char_p, _d], _n),
+    "mg_dist_info": ([_p, C.POINTER(_n), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _n),
+    "mg_dist_upload": ([_p, _n, _p, _i], _n),
+    "mg_dist_download": ([_p, _n, _p, _i], _n),
+    "mg_dist_presmooth": ([_p], _n),
+    "mg_dist_cycles": ([_p, _n, C.POINTER(_d)], _n),
+    "mg_dist_solve": ([_p, _d, C.POINTER(_n), C.POINTER(_d)], _n),
+    "mg_dist_history": ([_p, C.POINTER(_d), _n, C.POINTER(_n), C.POINTER(_n)], _n),
 }
+DIST_LOOPBACK = 64
 SOLVER_FIX_COARSE_ASCENT, SOLVER_REDBLACK, SOLVER_NO_GRAPH, SOLVER_LAZY_DEAD_LEVELS, SOLVER_TUNE_PLACEMENT, SOLVER_NO_PLACEMENT = 1, 2, 4, 8, 16, 32
 SOLVER_ARRAYS = {"x": 0, "b": 1, "r": 2, "xw": 3, "bw": 4, "rw": 5}
 
@@ -109,14 +120,18 @@ def lib():
     return _lib
 
 
+# host-only units of the library: what they hold cannot change a kernel's memory traffic
+_HOST_ONLY_SOURCES = ("mg_comm.hip", "mg_solver.hip", "mg_solver_dist.hip", "mg_runtime.hip")
+
+
 def sources_digest():
-    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile and include/mg_hip.h, by name): identifies the
-    kernel build that measurements kept under profiles/ (HBM traffic counters) belong to."""
+    """sha256 over the kernel sources (csrc/*.hip and *.h except the host-only units, and the Makefile with its compiler
+    flags, by name): identifies the kernel build that measurements kept under profiles/ (HBM traffic counters) belong to."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
-                   [os.path.join(_HERE, "csrc", "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "mg_hip.h")])
+    files = sorted(f for f in glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
+                   if os.path.basename(f) not in _HOST_ONLY_SOURCES) + [os.path.join(_HERE, "csrc", "Makefile")]
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:

@@ -786,10 +786,7 @@ class SlabMultigrid:
 
     def _smooth_level0(self, n, want_norm, crs=None, store_r=False):
         xs = [self._xa[0], self._xb[0]]
-        if not self._b0_halo_valid:  # b0 only changes when the caller sets it
-            if self.fused and self.world > 1:
-                self._exchange([(self.b[0], self.plan.levels[0], self.plan.halo - 1)])
-            self._b0_halo_valid = True
+        self._ensure_b0_halo()
         # the residual of the finest level is restricted right away: b_1 is ready for the next descent
         store_r = store_r or self.store_residual_every_cycle or not self.fused
         res = self._smooth(0, xs[self._cur0], crs, n, self.r[0] if store_r else None, self._norms[self._cur0] if want_norm else None,
@@ -913,7 +910,15 @@ class SlabMultigrid:
             self._flush_pending()
 
     # ------------------------------------------------------------------ drivers
+    def _ensure_b0_halo(self):
+        """The halo rows of the finest right-hand side, exchanged once after the caller has set it."""
+        if not self._b0_halo_valid:  # b0 only changes when the caller sets it
+            if self.fused and self.world > 1:
+                self._exchange([(self.b[0], self.plan.levels[0], self.plan.halo - 1)])
+            self._b0_halo_valid = True
+
     def _run_cycle(self, store_r=False):
+        self._ensure_b0_halo()  # never inside a captured cycle, which is replayed for right-hand sides to come
         self._last_parity = self._cur0  # selects the norm accumulator this cycle fills
         store_r = bool(store_r) and self.fused and not self.store_residual_every_cycle
         if self._whole_graph:

@@ -105,3 +105,109 @@ class NativeSolver:
             self.close()
         except Exception:
             pass
+
+
+class NativeDistSolver:
+    """The C handle API of the solver on several GPUs (mg_dist_*, include/mg_hip.h): one object per rank (process), the
+    grid cut into row slabs, halo exchanges / all-gather / norm reduction as raw RCCL calls of the library, a rank's whole
+    cycle one hipGraph launch.  `comm`: an mg_comm handle (ctypes pointer) of `world` ranks -- `from_torch_group` takes the
+    communicator of a torch.distributed `nccl` group.  Arrays handed in and out are the rank's owned rows of the finest
+    level (`owned_rows` rows from global row `first_row`), numpy or CUDA tensors."""
+
+    def __init__(self, gny, gnx, n_para, h0, comm, rank, world, *, dist_levels=0, fix_coarse_ascent=False,
+                 coarse_ordering="lexicographic", use_graph=True, eager_dead_levels=True, jacobi_omega=1.0, max_cycles=100,
+                 recompute_min_nx=None, recompute_min_blocks=None, loopback=False):
+        self.L = _lib.lib()
+        flags = (_lib.SOLVER_FIX_COARSE_ASCENT if fix_coarse_ascent else 0) | \
+                (_lib.SOLVER_REDBLACK if coarse_ordering == "redblack" else 0) | \
+                (0 if use_graph else _lib.SOLVER_NO_GRAPH) | (0 if eager_dead_levels else _lib.SOLVER_LAZY_DEAD_LEVELS) | \
+                (_lib.DIST_LOOPBACK if loopback else 0)
+        h = C.c_void_p()
+        check(self.L.mg_dist_create(gny, gnx, n_para, h0, flags, comm, rank, world, dist_levels, C.byref(h)))
+        self._h, self._own_comm = h, None
+        self.gny, self.gnx, self.n_para, self.rank, self.world = gny, gnx, n_para, rank, world
+        self.it = 0
+        for key, val in (("jacobi_omega", jacobi_omega if jacobi_omega != 1.0 else None), ("max_cycles", max_cycles if max_cycles != 100 else None),
+                         ("recompute_min_nx", recompute_min_nx), ("recompute_min_blocks", recompute_min_blocks)):
+            if val is not None:
+                check(self.L.mg_dist_set(self._h, key.encode(), float(val)))
+
+    @classmethod
+    def from_torch_group(cls, gny, gnx, n_para, h0, group=None, device=None, **kw):
+        """Rank and size from torch.distributed, the communicator from the group's `nccl` backend."""
+        import torch
+        import torch.distributed as dist
+
+        from .comm import loaded_rccl_path, torch_nccl_comm
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        t = torch.zeros(1, device=device)
+        dist.all_reduce(t, group=group)  # the communicator exists once it has carried a collective
+        L = _lib.lib()
+        c = C.c_void_p()
+        path = loaded_rccl_path()
+        check(L.mg_comm_attach(C.c_void_p(torch_nccl_comm(group, device)), path.encode() if path else None, C.byref(c)))
+        self = cls(gny, gnx, n_para, h0, c, dist.get_rank(group), dist.get_world_size(group), **kw)
+        self._own_comm = c
+        return self
+
+    def info(self):
+        nd, first, own, rounds = C.c_int(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.L.mg_dist_info(self._h, C.byref(nd), C.byref(first), C.byref(own), C.byref(rounds)))
+        return {"n_dist": nd.value, "first_row": first.value, "owned_rows": own.value, "rounds": rounds.value}
+
+    def _ptr(self, a, rows):
+        if hasattr(a, "data_ptr"):  # a torch tensor, host or device
+            if a.dim() != 2 or a.shape != (rows, self.gnx) or a.stride(1) != 1 or str(a.dtype) != "torch.float64":
+                raise MgError(f"expected a ({rows}, {self.gnx}) float64 array with unit column stride")
+            return a.data_ptr(), a.stride(0)
+        a = np.asarray(a)
+        if a.dtype != np.float64 or a.shape != (rows, self.gnx) or a.strides[1] != 8 or a.strides[0] % 8:
+            raise MgError(f"expected a ({rows}, {self.gnx}) float64 array with unit column stride")
+        return a.ctypes.data, a.strides[0] // 8
+
+    def upload(self, name, a):
+        p, ld = self._ptr(a, self.info()["owned_rows"])
+        check(self.L.mg_dist_upload(self._h, _lib.SOLVER_ARRAYS[name], p, ld))
+
+    def download(self, name, out=None):
+        rows = self.info()["owned_rows"]
+        if out is None:
+            out = np.empty((rows, self.gnx))
+        p, ld = self._ptr(out, rows)
+        check(self.L.mg_dist_download(self._h, _lib.SOLVER_ARRAYS[name], p, ld))
+        return out
+
+    def presmooth(self):
+        check(self.L.mg_dist_presmooth(self._h))
+
+    def cycles(self, k):
+        errs = (C.c_double * max(k, 1))()
+        check(self.L.mg_dist_cycles(self._h, k, errs))
+        return list(errs)[:k]
+
+    def solve(self, eps):
+        it, err = C.c_int(), C.c_double()
+        check(self.L.mg_dist_solve(self._h, eps, C.byref(it), C.byref(err)))
+        self.it = it.value
+        return err.value
+
+    def history(self):
+        n, div = C.c_int(), C.c_int()
+        check(self.L.mg_dist_history(self._h, None, 0, C.byref(n), C.byref(div)))
+        errs = (C.c_double * max(n.value, 1))()
+        check(self.L.mg_dist_history(self._h, errs, n.value, C.byref(n), C.byref(div)))
+        return list(errs)[: n.value], bool(div.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.mg_dist_destroy(self._h)
+            self._h = None
+        if getattr(self, "_own_comm", None):
+            self.L.mg_comm_destroy(self._own_comm)
+            self._own_comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

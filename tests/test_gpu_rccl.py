@@ -178,6 +178,41 @@ def _worker(port, q):
             pair.append((errs, eng.local_rows(eng.x0).cpu().numpy(), eng.local_rows(eng.r0).cpu().numpy()))
             eng.close()
         graph_comm_ok = pair[0][0] == pair[1][0] and np.array_equal(pair[0][1], pair[1][1]) and np.array_equal(pair[0][2], pair[1][2])
+        # the C handle of the several-rank solver (mg_dist_*), rehearsed the same way (MG_DIST_LOOPBACK): the same calls on
+        # the same rows in the same order as the engine with its whole cycle in one graph, so the same (meaningless) values
+        from multigrid_amd.comm import loaded_rccl_path
+        from multigrid_amd.solver import NativeDistSolver
+        import ctypes as C
+        from multigrid_amd import _lib
+        handle_ok = True
+        for world, rank, gny_, gnx_, npara_ in ((8, 3, 8 * 1024 + 1, 1025, 6), (2, 0, 2 * 2048 + 1, 513, 5), (4, 3, 4 * 512 + 1, 2049, 4)):
+            ops4 = HipOps(torch.device("cuda", 0))
+            lc = LoopbackComm(ops4, world, rank, rccl=True, native=True)
+            eng = SlabMultigrid(gny_, gnx_, npara_, 0.01, 0.0, ops=ops4, world=world, rank=rank, comm=lc, eager_dead_levels=True,
+                                dist_min_rows=64, graph_comm=True)
+            a, e = eng.owned_rows()
+            rows_b = np.random.default_rng(11 + world).standard_normal((e - a, gnx_))
+            eng.set_b_rows(torch.from_numpy(rows_b).cuda())
+            eng.presmooth()
+            errs_e = eng.cycles(3)
+            x_e, r_e = eng.local_rows(eng.x0).cpu().numpy(), eng.local_rows(eng.r0).cpu().numpy()
+            n_dist = eng.n_dist
+            eng.close()
+            c = C.c_void_p()
+            path = loaded_rccl_path()
+            _lib.check(_lib.lib().mg_comm_attach(C.c_void_p(torch_nccl_comm(None, ops.device)), path.encode() if path else None, C.byref(c)))
+            for graph in (True, False):
+                hs = NativeDistSolver(gny_, gnx_, npara_, 0.01, c, rank, world, dist_levels=n_dist, loopback=True, use_graph=graph)
+                assert hs.info()["n_dist"] == n_dist and hs.info()["owned_rows"] == e - a
+                hs.upload("b", rows_b)
+                hs.presmooth()
+                errs_h = hs.cycles(3)
+                same = errs_h == errs_e and np.array_equal(hs.download("x"), x_e) and np.array_equal(hs.download("r"), r_e)
+                handle_ok = handle_ok and same
+                print(f"C handle, rank {rank} of {world}, graph {graph}: equals the engine: {same}", flush=True)
+                hs.close()
+            _lib.lib().mg_comm_destroy(c)
+        graph_comm_ok = graph_comm_ok and handle_ok
         print("loopback engine runs:", engine_runs, "whole-cycle graph with exchanges equals eager:", graph_comm_ok, flush=True)
         graphs_ok = graphs_ok and graph_comm_ok
         graphs_ok = graphs_ok and all(r[0] == 3 and r[1] and r[2] == r[3] and r[4] and r[5] and r[6] for r in engine_runs)

@@ -1,5 +1,6 @@
 """The slab engine over real RCCL: one process per GPU, `nccl` backend, 2 ranks and as many as there are devices
-(at most 8).  Runs wherever at least two devices are visible and is skipped on a one-GPU lease -- there the same
+(at most 8): the Python engine launching pass by pass (its exchanges raw RCCL groups of the library), the same with a
+rank's whole cycle captured into one hipGraph, and the C handle mg_dist_*.  Runs wherever at least two devices are visible and is skipped on a one-GPU lease -- there the same
 schedule is covered by the gloo tests (ranks sharing the GPU, tests/test_gpu_multirank.py) and the one-rank RCCL
 calls (tests/test_gpu_rccl.py).  Every rank keeps 4096 rows of a 4097-column grid, so the multi-rank grid is
 (world * 4096 + 1) x 4097; every pass that follows an exchange is cut around it (overlap_min_rows = 1).  Results must
@@ -28,7 +29,7 @@ def _device_count():
         return 0
 
 
-def _worker(rank, world, port, use_graph, q):
+def _worker(rank, world, port, use_graph, q, mode="engine"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -44,17 +45,33 @@ def _worker(rank, world, port, use_graph, q):
         from multigrid_amd.engine import SlabMultigrid
         gny = world * ROWS + 1
         h = 20.0 / (GNX - 1)
-        eng = SlabMultigrid(gny, GNX, N_PARA, h, 0.0, world=world, rank=rank, eager_dead_levels=True, overlap_min_rows=1,
-                            use_graph=use_graph)
-        assert eng.comm.staged == REHEARSE and dist.get_world_size() == world
-        a, e = eng.owned_rows()
         rng = np.random.default_rng(100 + rank)  # every rank makes its own rows; the parent rebuilds the same grid
-        rows = rng.standard_normal((e - a, GNX))
+        rows = rng.standard_normal((ROWS + (1 if rank == world - 1 else 0), GNX))
         rows[:, 0] = rows[:, -1] = 0
         if rank == 0:
             rows[0] = 0
         if rank == world - 1:
             rows[-1] = 0
+        if mode == "handle":  # the C handle: mg_dist_* on the group's communicator, a rank's cycle one graph launch
+            from multigrid_amd.solver import NativeDistSolver
+            s = NativeDistSolver.from_torch_group(gny, GNX, N_PARA, h, use_graph=use_graph)
+            assert s.info()["owned_rows"] == rows.shape[0] and s.info()["first_row"] == rank * ROWS
+            s.upload("b", rows)
+            s.presmooth()
+            errs = s.cycles(CYCLES)
+            before = s.info()["rounds"]
+            errs += s.cycles(1)
+            rounds = s.info()["rounds"] - before
+            q.put((rank, errs, s.download("x"), s.download("r"), rounds, rounds, s.info()["n_dist"], 1))
+            dist.barrier()
+            s.close()
+            return
+        eng = SlabMultigrid(gny, GNX, N_PARA, h, 0.0, world=world, rank=rank, eager_dead_levels=True, overlap_min_rows=1,
+                            use_graph=use_graph, graph_comm=mode == "graph_comm")
+        assert eng.comm.staged == REHEARSE and dist.get_world_size() == world
+        assert eng.graph_comm == (mode == "graph_comm" and use_graph and not REHEARSE)
+        a, e = eng.owned_rows()
+        assert e - a == rows.shape[0]
         eng.set_b_rows(torch.from_numpy(rows).cuda())
         eng.presmooth()
         errs = eng.cycles(CYCLES)
@@ -63,11 +80,20 @@ def _worker(rank, world, port, use_graph, q):
         rounds = eng.comm.rounds - before
         x = eng.local_rows(eng.x0).cpu().numpy()
         r = eng.local_rows(eng.r0).cpu().numpy()
-        q.put((rank, errs, x, r, rounds, eng.rounds_per_cycle(), eng.n_dist, eng.split_passes))
+        per_cycle = eng.rounds_per_cycle()
+        if eng.graph_comm:  # the rounds are inside the graph, which is not cut: nothing to count here
+            rounds, per_cycle, cut = 0, 0, 1
+        else:
+            cut = eng.split_passes
+        q.put((rank, errs, x, r, rounds, per_cycle, eng.n_dist, cut))
         dist.barrier()
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_mode(rank, world, port, use_graph, mode, q):
+    _worker(rank, world, port, use_graph, q, mode)
 
 
 def _worlds():
@@ -78,11 +104,14 @@ def _worlds():
 
 
 @pytest.mark.skipif(_device_count() < 2 and not REHEARSE, reason="needs at least two GPUs (RCCL refuses two ranks on one device)")
-@pytest.mark.parametrize("use_graph", [True, False], ids=["graph", "eager"])
-def test_slab_engine_over_rccl_equals_oracle(use_graph):
+@pytest.mark.parametrize("use_graph,mode", [(True, "engine"), (False, "engine"), (True, "graph_comm"), (True, "handle"), (False, "handle")],
+                         ids=["graph", "eager", "whole-cycle-graph", "c-handle-graph", "c-handle-eager"])
+def test_slab_engine_over_rccl_equals_oracle(use_graph, mode):
     from tests.mp_util import run_ranks
+    if REHEARSE and mode == "handle":
+        pytest.skip("the C handle talks to RCCL only")
     for world in _worlds():
-        out = run_ranks(_worker, world, (use_graph,), timeout=280)
+        out = run_ranks(_worker_mode, world, (use_graph, mode), timeout=280)
         gny = world * ROWS + 1
         b = np.zeros((gny, GNX))
         for rank in range(world):

@@ -228,3 +228,35 @@ def test_handle_cycles_run_at_the_engines_rate():
     assert np.array_equal(s.download("x"), eng.local_rows(eng.x0).cpu().numpy())
     s.close()
     eng.close()
+
+
+@pytest.mark.parametrize("gny,gnx,n_para,graph,recompute", [(257, 257, 3, True, True), (1025, 513, 5, True, False), (513, 2049, 4, False, True)],
+                         ids=str)
+def test_dist_handle_on_one_rank_equals_oracle(gny, gnx, n_para, graph, recompute):
+    """mg_dist_* with world = 1 (no communicator): the several-rank solver's layout (twelve halo rows) and schedule on
+    one rank must equal the undecomposed oracle bit for bit, solve() with the stop rule included."""
+    from multigrid_amd.solver import NativeDistSolver
+    b = _rhs(gny, gnx, 3)
+    h = 0.37
+    kw = dict(recompute_min_nx=0, recompute_min_blocks=0) if recompute else {}
+    s = NativeDistSolver(gny, gnx, n_para, h, None, 0, 1, use_graph=graph, **kw)
+    assert s.info() == {"n_dist": 0, "first_row": 0, "owned_rows": gny, "rounds": 0}
+    s.upload("b", b)
+    s.presmooth()
+    errs = s.cycles(3)
+    ref = oracle.GlobalSolver(gny, gnx, n_para, h, 0.0)
+    ref.b[:] = b
+    ref.solve(ncycles=3)
+    assert errs == ref.err_hist.tolist()
+    assert np.array_equal(s.download("x"), ref.x) and np.array_equal(s.download("r"), ref.r)
+    # solve(): a fresh start with a tolerance; warm start afterwards
+    s.upload("x", np.zeros((gny, gnx)))
+    ref2 = oracle.GlobalSolver(gny, gnx, n_para, h, 0.05 * ref.err_hist[0])
+    ref2.b[:] = b
+    e_ref = ref2.solve()
+    assert s.solve(0.05 * ref.err_hist[0]) == e_ref and s.it == ref2.it
+    assert s.history()[0] == ref2.err_hist.tolist()
+    assert np.array_equal(s.download("x"), ref2.x)
+    s.close()
+    with pytest.raises(Exception):
+        NativeDistSolver(gny, gnx, n_para, h, None, 0, 2)  # several ranks need a communicator

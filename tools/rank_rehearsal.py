@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling: the (2**(n+1)+1)^2 grid cut into N slabs (bench.py --strong)")
     ap.add_argument("--rccl-high-priority", action="store_true", help="RCCL's own streams at high priority")
     ap.add_argument("--engine-args", default="{}", help="JSON dict of further SlabMultigrid keyword arguments")
+    ap.add_argument("--native", action="store_true",
+                    help="the C handle of the several-rank solver (mg_dist_*, MG_DIST_LOOPBACK) in the place of the Python engine: "
+                         "a rank's whole cycle, RCCL calls included, is one graph launch issued by the library")
     args = ap.parse_args()
 
     import torch
@@ -80,6 +83,8 @@ def main():
     gny = (1 if args.strong else world) * 2 ** (n + 1) + 1
     n_para = args.n_para or choose_n_para(gny, gnx, world, at_least=max(1, n - 4))
     h = 20.0 / 2 ** (n + 1)
+    if args.native:
+        return native(args, world, rank, gny, gnx, n_para, h, torch, dist)
     ops = HipOps()
     comm = LoopbackComm(ops, world, rank, rccl=args.comm != "copy", native=args.comm == "rccl") if world > 1 else None
     extra = json.loads(args.engine_args)
@@ -133,6 +138,48 @@ def main():
     eng.close()
     if args.comm != "copy":
         dist.destroy_process_group()
+
+
+def native(args, world, rank, gny, gnx, n_para, h, torch, dist):
+    import ctypes as C
+
+    import bench
+    from multigrid_amd import _lib
+    from multigrid_amd.comm import loaded_rccl_path, torch_nccl_comm
+    from multigrid_amd.engine import SlabMultigrid
+    from multigrid_amd.solver import NativeDistSolver
+    assert args.comm == "rccl" and world > 1, "--native rehearses the library's RCCL calls on a one-rank nccl group"
+    t = torch.zeros(1, device="cuda")
+    dist.all_reduce(t)
+    c = C.c_void_p()
+    path = loaded_rccl_path()
+    _lib.check(_lib.lib().mg_comm_attach(C.c_void_p(torch_nccl_comm(None, torch.device("cuda", 0))), path.encode() if path else None, C.byref(c)))
+    s = NativeDistSolver(gny, gnx, n_para, h, c, rank, world, loopback=True)
+    info = s.info()
+    # the rank's rows of the bench's right-hand side, made by the engine's own generator on a throw-away slab
+    L = SlabMultigrid(gny, gnx, n_para, h, 0.025, world=world, rank=rank, comm=type("C", (), {"staged": True, "mode": "none"})(),
+                      tune_placement=False, dist_levels=info["n_dist"])
+    bench.fill_rhs(L, torch, args.n, rank)
+    s.upload("b", L.local_rows(L.b0))
+    del L
+    torch.cuda.empty_cache()
+    s.presmooth()
+    s.cycles(args.warmup)
+    torch.cuda.synchronize()
+    r0 = s.info()["rounds"]
+    t0 = time.perf_counter()
+    s.cycles(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"world": world, "rank": rank, "comm": "rccl", "engine": "C handle (mg_dist_*), loopback", "scaling": "strong" if args.strong else "weak",
+           "grid": [gny, gnx], "n_para": n_para, "distributed_levels": info["n_dist"], "halo_rows": 12,
+           "ms_per_cycle": 1e3 * dt / args.steps, "order": "cycles", "rounds_per_cycle": (s.info()["rounds"] - r0) / args.steps}
+    # host time to issue a cycle: the library's own loop returns when the last cycle's norm has arrived, so the time the
+    # host is busy is measured on single-cycle calls minus the device's time for them
+    print(json.dumps(out), flush=True)
+    s.close()
+    _lib.lib().mg_comm_destroy(c)
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":
