@@ -125,17 +125,22 @@ _HOST_ONLY_SOURCES = ("mg_comm.hip", "mg_solver.hip", "mg_solver_dist.hip", "mg_
 
 
 def sources_digest():
-    """sha256 over the kernel sources (csrc/*.hip and *.h except the host-only units, and the Makefile with its compiler
-    flags, by name): identifies the kernel build that measurements kept under profiles/ (HBM traffic counters) belong to."""
+    """sha256 over the kernel sources (csrc/*.hip and *.h except the host-only units, by name) and the compiler settings
+    of the Makefile (its HIPCC / ARCH / FLAGS lines): identifies the kernel build that measurements kept under profiles/
+    (HBM traffic counters) belong to."""
     import glob
     import hashlib
     h = hashlib.sha256()
     files = sorted(f for f in glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
-                   if os.path.basename(f) not in _HOST_ONLY_SOURCES) + [os.path.join(_HERE, "csrc", "Makefile")]
+                   if os.path.basename(f) not in _HOST_ONLY_SOURCES)
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())
+    with open(os.path.join(_HERE, "csrc", "Makefile")) as fh:
+        for line in fh:
+            if line.split("?=")[0].split(":=")[0].strip() in ("HIPCC", "ARCH", "FLAGS"):
+                h.update(line.encode())
     return h.hexdigest()
 
 

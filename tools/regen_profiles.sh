@@ -6,10 +6,12 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/regen
 mkdir -p $O
 cd $R
+if [ -z "$SKIP_TRAFFIC" ]; then   # SKIP_TRAFFIC=1: profiles/traffic.json already belongs to these kernel sources
 bash tools/regen_traffic.sh > $O/traffic.txt 2>&1
 cp gpurun_out/traffic.json gpurun_out/r2_probe_pmc_fetch_size.csv gpurun_out/r2_probe_pmc_write_size.csv $O/
 cp gpurun_out/traffic.json profiles/traffic.json   # bench.py prints the table only when it fits the kernel sources
 echo pmc done
+fi
 timeout -k 10 400 python3 bench.py > $O/bench_n14.json
 echo bench done
 cd /tmp && export TMPDIR=/tmp
