@@ -294,6 +294,10 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     if world > 1:
+        # a rank that is still here after ten minutes writes every thread's stack to standard error and ends: a hang among
+        # the ranks then shows where each of them waits instead of running into the launcher's time limit without a word
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("MG_BENCH_WATCHDOG_S", "600")), exit=True, file=sys.stderr)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -556,6 +560,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
         dist.destroy_process_group()
 
 

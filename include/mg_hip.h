@@ -414,7 +414,9 @@ int mg_solver_history(mg_solver *s, double *errs, int capacity, int *count, int 
  *   mg_dist_create     collective: every rank calls it with the same grid, flags and dist_levels, its own rank, and a
  *                      communicator of `world` ranks in which it has that rank (mg_comm_attach / mg_comm_init; NULL
  *                      for world = 1).  flags: MG_SOLVER_FIX_COARSE_ASCENT, _REDBLACK, _NO_GRAPH, _LAZY_DEAD_LEVELS as
- *                      for mg_solver_create, and MG_DIST_LOOPBACK: a rehearsal of ONE rank of `world` alone, on a
+ *                      for mg_solver_create (MG_SOLVER_NO_PLACEMENT too: by default a rank whose finest arrays take
+ *                      >= 1 GiB each chooses their placement as mg_solver_create does; mg_dist_placement reports the
+ *                      number of candidates timed, -1: none), and MG_DIST_LOOPBACK: a rehearsal of ONE rank of `world` alone, on a
  *                      one-rank communicator with the rank as its own neighbours (values are meaningless then; the
  *                      calls, their sizes and their cost are the real job's).
  *   mg_dist_upload / mg_dist_download   the rank's OWNED rows of the finest-level b or x (download: also r), a host or
@@ -434,6 +436,7 @@ int mg_dist_create(int64_t gny, int64_t gnx, int n_para, double h0, int flags, m
 int mg_dist_destroy(mg_dist_solver *s);
 int mg_dist_set(mg_dist_solver *s, const char *key, double value);
 int mg_dist_info(mg_dist_solver *s, int *n_dist, int64_t *first_global_row, int64_t *owned_rows, int64_t *rounds);
+int mg_dist_placement(mg_dist_solver *s, int *candidates);
 int mg_dist_upload(mg_dist_solver *s, int which, const double *src, int64_t src_ld);
 int mg_dist_download(mg_dist_solver *s, int which, double *dst, int64_t dst_ld);
 int mg_dist_presmooth(mg_dist_solver *s);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "mg_dist_destroy": ([_p], _n),
     "mg_dist_set": ([_p, C.c_char_p, _d], _n),
     "mg_dist_info": ([_p, C.POINTER(_n), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _n),
+    "mg_dist_placement": ([_p, C.POINTER(_n)], _n),
     "mg_dist_upload": ([_p, _n, _p, _i], _n),
     "mg_dist_download": ([_p, _n, _p, _i], _n),
     "mg_dist_presmooth": ([_p], _n),

@@ -162,3 +162,19 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v)
     }
     return v;
 }
+
+// ---- placement selection of the finest level's arrays (mg_solver.hip; used by both solver handles) ------------------
+// The shapes and row geometry of the finest pass as the caller's cycle launches it, and of level 1's 9-stage pass.
+struct MgPlaceShape {
+    hipStream_t stream;
+    i64 ny, nx, ld;                    // a finest-level array
+    i64 cny, cnx, cld;                 // the array the finest pass restricts into (the correction it reads has that shape too)
+    i64 j0, j1, flo, fhi, oj, T0, T1;  // rows the pass produces, Dirichlet rows, row offset of the transfers, coarse rows
+    double h0;
+    bool level1;                       // also choose level 1's x (it runs the 9-stage pass with recomputed pre-smoothing)
+    i64 c2ny, c2nx, c2ld;              // level 2's x, which that pass prolongs
+    i64 j0_1, j1_1, flo_1, fhi_1;      // its row geometry on level 1
+};
+// fin[] = {xa, xb, b, r} of the finest level, *cb_out = the array it restricts into, *xa1_out = level 1's x: all zeroed, or
+// all null when the level is small (< 1 GiB per array), memory is short or anything fails.  *candidates_out: candidates timed.
+void mg_place_finest(const MgPlaceShape &P, double *fin[4], double **cb_out, double **xa1_out, int *candidates_out);

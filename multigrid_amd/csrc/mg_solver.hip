@@ -306,13 +306,16 @@ int collect_err(mg_solver *s, int a, double *err)
 // No new candidate is allocated once 1.5 s have passed (an 8-GiB allocation takes 5 to 200 ms).  fin[] and *cb_out
 // stay null when the level is small (< 1 GiB per array), memory is short or anything fails: create then allocates
 // as usual.
-void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_out)
+} // namespace
+
+void mg_place_finest(const MgPlaceShape &P, double *fin[4], double **cb_out, double **xa1_out, int *candidates_out)
 {
+    struct { hipStream_t stream; } sh{P.stream}, *s = &sh; // (the body below names the stream s->stream)
     const int KMAX = 26, SPREAD = 14;
     const double BUDGET = 1.5;
     const auto t_begin = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
-    const i64 ny = s->gny, nx = s->gnx, ld = pitch(nx), n = ny * ld;
+    const i64 ny = P.ny, nx = P.nx, ld = P.ld, n = ny * ld;
     const size_t bytes = (size_t)n * sizeof(double);
     for (int k = 0; k < 4; ++k) fin[k] = nullptr;
     *cb_out = nullptr, *xa1_out = nullptr;
@@ -323,7 +326,7 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
     int kmax = free_b > reserve ? (int)((free_b - reserve) / bytes) : 0;
     if (kmax > KMAX) kmax = KMAX;
     if (kmax < 6) return;
-    const i64 cny = ((ny - 1) >> 1) + 1, cnx = ((nx - 1) >> 1) + 1, cld = pitch(cnx); // the next level, Jacobi or whole-domain
+    const i64 cny = P.cny, cnx = P.cnx, cld = P.cld; // the next level, Jacobi or whole-domain
     const size_t cbytes = (size_t)(cny * cld) * sizeof(double);
     double *crs = nullptr, *cb = nullptr;
     u64 *norm = nullptr;
@@ -336,8 +339,8 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
     auto time_pass = [&](double *b, double *xin, double *xout, float *ms, const double *corr = nullptr) { // the launch of finest_pass; the first one is not timed
         bool good = true;
         for (int rep = 0; rep < 3 && good; ++rep) {
-            good = !mg_smooth_fused_restrict(b, xin, xout, nullptr, corr ? corr : crs, ny, nx, ld, cny, cnx, cld, 1, ny - 1, 0, ny - 1, 0, N2,
-                                             s->h0, 1.0, (uint64_t *)norm, 0, cb, cny, cnx, cld, 1, cny - 1, 1, 0, 0, 0, s->stream);
+            good = !mg_smooth_fused_restrict(b, xin, xout, nullptr, corr ? corr : crs, ny, nx, ld, cny, cnx, cld, P.j0, P.j1, P.flo, P.fhi, P.oj, N2,
+                                             P.h0, 1.0, (uint64_t *)norm, 0, cb, cny, cnx, cld, P.T0, P.T1, 1, 0, 0, 0, s->stream);
             if (rep == 0) good = good && hipEventRecord(e0, s->stream) == hipSuccess;
         }
         good = good && hipEventRecord(e1, s->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
@@ -428,7 +431,7 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
             fin[q] = a[pick[q]];
             a[pick[q]] = nullptr;
         }
-        if (ok) s->placement_candidates = nt, *cb_out = cb, cb = nullptr;
+        if (ok) *candidates_out = nt, *cb_out = cb, cb = nullptr;
     }
     // (the candidates not chosen are still held: the next level's candidates then come from further along the sequence of
     // allocations, not from the memory these give back, which is the stretch the level's right-hand side lies in)
@@ -436,14 +439,12 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
     // depending on the allocation it writes its x into), where that is the 9-stage pass with recomputed
     // pre-smoothing.  Up to eight candidates are timed as its output beside the level's right-hand side (the array
     // kept above); the fastest becomes the level's x.
-    if (ok && *cb_out && s->n_para >= 3) {
-        const i64 strips = (cnx + 107) / 108, blocks = ((strips + 3) / 4) * ((cny - 1 + 63) / 64);
-        const i64 c2ny = ((ny - 1) >> 2) + 1, c2nx = ((nx - 1) >> 2) + 1, c2ld = pitch(c2nx);
+    if (ok && *cb_out && P.level1) {
+        const i64 c2ny = P.c2ny, c2nx = P.c2nx, c2ld = P.c2ld;
         double *crs2 = nullptr, *cand[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         float t1[8], tf[8], lo1 = 0, hi1 = 0; // ms of the level's pass into the candidate; of the finest pass reading it
         int n1 = 0;
-        bool ok1 = cnx >= s->recompute_min_nx && blocks >= s->recompute_min_blocks &&
-                   hipMalloc((void **)&crs2, (size_t)(c2ny * c2ld) * sizeof(double)) == hipSuccess &&
+        bool ok1 = hipMalloc((void **)&crs2, (size_t)(c2ny * c2ld) * sizeof(double)) == hipSuccess &&
                    hipMemsetAsync(crs2, 0, (size_t)(c2ny * c2ld) * sizeof(double), s->stream) == hipSuccess;
         while (ok1 && n1 < 8) {
             if (hipMalloc((void **)&cand[n1], cbytes) != hipSuccess) {
@@ -452,8 +453,8 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
             }
             ok1 = hipMemsetAsync(cand[n1], 0, cbytes, s->stream) == hipSuccess;
             for (int rep = 0; rep < 3 && ok1; ++rep) {
-                ok1 = !mg_smooth_fused(*cb_out, nullptr, cand[n1], nullptr, crs2, cny, cnx, cld, c2ny, c2nx, c2ld, 1, cny - 1, 0, cny - 1,
-                                       0, N1 + N2, N1, 2 * s->h0, 1.0, nullptr, 1, 0, 0, s->stream);
+                ok1 = !mg_smooth_fused(*cb_out, nullptr, cand[n1], nullptr, crs2, cny, cnx, cld, c2ny, c2nx, c2ld, P.j0_1, P.j1_1, P.flo_1,
+                                       P.fhi_1, P.oj, N1 + N2, N1, 2 * P.h0, 1.0, nullptr, 1, 0, 0, s->stream);
                 if (rep == 0) ok1 = ok1 && hipEventRecord(e0, s->stream) == hipSuccess;
             }
             ok1 = ok1 && hipEventRecord(e1, s->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
@@ -495,7 +496,7 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
         if (*cb_out) (void)hipFree(*cb_out);
         if (*xa1_out) (void)hipFree(*xa1_out);
         *cb_out = *xa1_out = nullptr;
-        s->placement_candidates = -1;
+        *candidates_out = -1;
     }
     for (int k = 0; k < na; ++k)
         if (a[k]) (void)hipFree(a[k]);
@@ -504,6 +505,25 @@ void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_ou
     if (norm) (void)hipFree(norm);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+}
+
+
+namespace {
+
+// the one-GPU handle's shapes for mg_place_finest
+void place_finest(mg_solver *s, double *fin[4], double **cb_out, double **xa1_out)
+{
+    MgPlaceShape P;
+    P.stream = s->stream;
+    P.ny = s->gny, P.nx = s->gnx, P.ld = pitch(P.nx);
+    P.cny = ((P.ny - 1) >> 1) + 1, P.cnx = ((P.nx - 1) >> 1) + 1, P.cld = pitch(P.cnx);
+    P.j0 = 1, P.j1 = P.ny - 1, P.flo = 0, P.fhi = P.ny - 1, P.oj = 0, P.T0 = 1, P.T1 = P.cny - 1;
+    P.h0 = s->h0;
+    const i64 strips = (P.cnx + 107) / 108, blocks = ((strips + 3) / 4) * ((P.cny - 1 + 63) / 64);
+    P.level1 = s->n_para >= 3 && P.cnx >= s->recompute_min_nx && blocks >= s->recompute_min_blocks; // level 1 runs the 9-stage pass
+    P.c2ny = ((P.ny - 1) >> 2) + 1, P.c2nx = ((P.nx - 1) >> 2) + 1, P.c2ld = pitch(P.c2nx);
+    P.j0_1 = 1, P.j1_1 = P.cny - 1, P.flo_1 = 0, P.fhi_1 = P.cny - 1;
+    mg_place_finest(P, fin, cb_out, xa1_out, &s->placement_candidates);
 }
 
 } // namespace

@@ -74,6 +74,7 @@ struct mg_dist_solver {
     int graph_end_cur[2];
     int cur0, last_acc, it;
     bool r_stale, b0_halo_valid, diverged;
+    int placement_candidates; // candidate arrays the placement selection timed, -1: none
     i64 rounds;           // exchange rounds and all-gathers carried out so far
     i64 rounds_per_graph; // ... that one replay of a captured cycle carries out
     std::vector<double> hist;
@@ -500,7 +501,8 @@ extern "C" int mg_dist_create(int64_t gny, int64_t gnx, int n_para, double h0, i
                "mg_dist_create: rows-1 (%lld) and columns-1 (%lld) must be divisible by 2^n_para", (long long)(gny - 1), (long long)(gnx - 1));
     MG_REQUIRE(((gny - 1) >> n_para) >= 2 && ((gnx - 1) >> n_para) >= 2, "mg_dist_create: the first whole-domain level needs at least 2 cells per side");
     MG_REQUIRE(h0 > 0, "mg_dist_create: mesh width must be positive");
-    MG_REQUIRE((flags & ~(MG_SOLVER_FIX_COARSE_ASCENT | MG_SOLVER_REDBLACK | MG_SOLVER_NO_GRAPH | MG_SOLVER_LAZY_DEAD_LEVELS | MG_DIST_LOOPBACK)) == 0,
+    MG_REQUIRE((flags & ~(MG_SOLVER_FIX_COARSE_ASCENT | MG_SOLVER_REDBLACK | MG_SOLVER_NO_GRAPH | MG_SOLVER_LAZY_DEAD_LEVELS | MG_SOLVER_NO_PLACEMENT |
+                          MG_DIST_LOOPBACK)) == 0,
                "mg_dist_create: unknown flag bits in %d", flags);
     const bool loopback = flags & MG_DIST_LOOPBACK;
     int crank = 0, cworld = 1;
@@ -534,7 +536,7 @@ extern "C" int mg_dist_create(int64_t gny, int64_t gnx, int n_para, double h0, i
     s->stream = s->side = s->copy = nullptr, s->fork = s->join = nullptr;
     s->filled[0] = s->filled[1] = s->fetched[0] = s->fetched[1] = nullptr;
     for (int a = 0; a < 2; ++a) s->graphs[a][0] = s->graphs[a][1] = nullptr, s->graph_end_cur[a] = 0;
-    s->cur0 = 0, s->last_acc = 0, s->it = 0, s->r_stale = true, s->b0_halo_valid = false, s->diverged = false, s->rounds = 0, s->rounds_per_graph = 0;
+    s->cur0 = 0, s->last_acc = 0, s->it = 0, s->r_stale = true, s->b0_halo_valid = false, s->diverged = false, s->rounds = 0, s->rounds_per_graph = 0, s->placement_candidates = -1;
     int rc = 1;
     do {
         if (hipGetDevice(&s->device) != hipSuccess) { mg_set_error("mg_dist_create: no current device"); break; }
@@ -553,16 +555,58 @@ extern "C" int mg_dist_create(int64_t gny, int64_t gnx, int n_para, double h0, i
             break;
         }
         bool ok = true;
+        for (int l = 0; l <= (world > 1 ? n_dist : -1); ++l) s->slab.push_back(make_level(gny, gnx, l, world, rank, h0, true));
+        // Where the finest level's arrays lie decides how fast the finest pass runs (see mg_place_finest): on grids of at least
+        // 1 GiB per array create chooses them among candidate allocations, timed as the outputs of that pass, and keeps the
+        // array the pass restricts into (level 1's right-hand side, or the slab that is all-gathered) and level 1's x with them.
+        double *fin[4] = {nullptr, nullptr, nullptr, nullptr}, *cb1 = nullptr, *xa1 = nullptr;
+        const bool slab1 = world > 1 && n_dist == 1; // the finest pass restricts into the slab that is all-gathered
+        if (!(flags & MG_SOLVER_NO_PLACEMENT)) {
+            const DLevel F = make_level(gny, gnx, 0, world, rank, h0, true), C = make_level(gny, gnx, 1, world, rank, h0, true),
+                         C2 = make_level(gny, gnx, 2, world, rank, h0, true);
+            MgPlaceShape P;
+            P.stream = s->stream;
+            P.ny = F.ny, P.nx = F.nx, P.ld = F.ld, P.cny = C.ny, P.cnx = C.nx, P.cld = C.ld;
+            P.j0 = F.t0, P.j1 = F.t1, P.flo = F.flo, P.fhi = F.fhi, P.oj = -HALO, P.T0 = C.t0, P.T1 = C.t1;
+            P.h0 = h0;
+            const i64 strips = (C.nx + 107) / 108, blocks = ((strips + 3) / 4) * ((C.rows + 63) / 64);
+            // level 1's x is chosen with them where level 1 is a slab like the finest level and runs the 9-stage pass
+            P.level1 = n_para >= 3 && (world == 1 || n_dist >= 2) &&
+                       ((C.nx >= s->recompute_min_nx && blocks >= s->recompute_min_blocks) || (world > 1 && n_dist == 2));
+            P.c2ny = C2.ny, P.c2nx = C2.nx, P.c2ld = C2.ld, P.j0_1 = C.t0, P.j1_1 = C.t1, P.flo_1 = C.flo, P.fhi_1 = C.fhi;
+            mg_place_finest(P, fin, &cb1, &xa1, &s->placement_candidates);
+            for (int q = 0; q < 4; ++q)
+                if (fin[q]) s->allocs.push_back(fin[q]);
+            if (cb1) s->allocs.push_back(cb1);
+            if (xa1) s->allocs.push_back(xa1);
+        }
         for (int l = 0; l <= n_para && ok; ++l) {
             const bool dist = world > 1 && l < n_dist;
             DLevel L = dist ? make_level(gny, gnx, l, world, rank, h0, true) : make_level(gny, gnx, l, 1, 0, h0, false);
-            if (l < n_para) ok = !dev_alloc(s, &L.xa, L.ny * L.ld) && !dev_alloc(s, &L.xb, L.ny * L.ld);
-            ok = ok && !dev_alloc(s, &L.b, L.ny * L.ld);
-            if (ok && l == 0) ok = !dev_alloc(s, &L.r, L.ny * L.ld);
+            if (l == 0 && fin[0]) { // placed (and left all zero) by mg_place_finest
+                L.xa = fin[0], L.xb = fin[1], L.b = fin[2], L.r = fin[3];
+            } else {
+                if (l < n_para) {
+                    if (l == 1 && xa1 && !slab1)
+                        L.xa = xa1;
+                    else
+                        ok = !dev_alloc(s, &L.xa, L.ny * L.ld);
+                    ok = ok && !dev_alloc(s, &L.xb, L.ny * L.ld);
+                }
+                if (ok && l == 1 && cb1 && !slab1)
+                    L.b = cb1;
+                else
+                    ok = ok && !dev_alloc(s, &L.b, L.ny * L.ld);
+                if (ok && l == 0) ok = !dev_alloc(s, &L.r, L.ny * L.ld);
+            }
             s->lv.push_back(L);
         }
-        for (int l = 0; l <= (world > 1 ? n_dist : -1); ++l) s->slab.push_back(make_level(gny, gnx, l, world, rank, h0, true));
-        if (ok && world > 1) ok = !dev_alloc(s, &s->bslab, s->slab[n_dist].ny * s->slab[n_dist].ld);
+        if (ok && world > 1) {
+            if (slab1 && cb1)
+                s->bslab = cb1;
+            else
+                ok = !dev_alloc(s, &s->bslab, s->slab[n_dist].ny * s->slab[n_dist].ld);
+        }
         if (!ok) break;
         // whole-domain levels; the first shares the rows of the staging level's padded arrays (local row t = global row t - HALO)
         const DLevel &S = s->lv[n_para];
@@ -617,6 +661,13 @@ extern "C" int mg_dist_set(mg_dist_solver *s, const char *key, double value)
     MG_HIP(hipStreamSynchronize(s->stream));
     drop_graphs(s);
     decide_recompute(s);
+    return 0;
+}
+
+extern "C" int mg_dist_placement(mg_dist_solver *s, int *candidates)
+{
+    MG_REQUIRE(s && candidates, "mg_dist_placement: null argument");
+    *candidates = s->placement_candidates;
     return 0;
 }
 

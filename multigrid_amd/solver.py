@@ -116,12 +116,12 @@ class NativeDistSolver:
 
     def __init__(self, gny, gnx, n_para, h0, comm, rank, world, *, dist_levels=0, fix_coarse_ascent=False,
                  coarse_ordering="lexicographic", use_graph=True, eager_dead_levels=True, jacobi_omega=1.0, max_cycles=100,
-                 recompute_min_nx=None, recompute_min_blocks=None, loopback=False):
+                 recompute_min_nx=None, recompute_min_blocks=None, loopback=False, tune_placement=True):
         self.L = _lib.lib()
         flags = (_lib.SOLVER_FIX_COARSE_ASCENT if fix_coarse_ascent else 0) | \
                 (_lib.SOLVER_REDBLACK if coarse_ordering == "redblack" else 0) | \
                 (0 if use_graph else _lib.SOLVER_NO_GRAPH) | (0 if eager_dead_levels else _lib.SOLVER_LAZY_DEAD_LEVELS) | \
-                (_lib.DIST_LOOPBACK if loopback else 0)
+                (_lib.DIST_LOOPBACK if loopback else 0) | (0 if tune_placement else _lib.SOLVER_NO_PLACEMENT)
         h = C.c_void_p()
         check(self.L.mg_dist_create(gny, gnx, n_para, h0, flags, comm, rank, world, dist_levels, C.byref(h)))
         self._h, self._own_comm = h, None
@@ -149,6 +149,12 @@ class NativeDistSolver:
         self = cls(gny, gnx, n_para, h0, c, dist.get_rank(group), dist.get_world_size(group), **kw)
         self._own_comm = c
         return self
+
+    @property
+    def placement_candidates(self):
+        g = C.c_int()
+        check(self.L.mg_dist_placement(self._h, C.byref(g)))
+        return None if g.value < 0 else g.value
 
     def info(self):
         nd, first, own, rounds = C.c_int(), C.c_int64(), C.c_int64(), C.c_int64()
