@@ -260,3 +260,41 @@ def test_dist_handle_on_one_rank_equals_oracle(gny, gnx, n_para, graph, recomput
     s.close()
     with pytest.raises(Exception):
         NativeDistSolver(gny, gnx, n_para, h, None, 0, 2)  # several ranks need a communicator
+
+
+def test_c_program_on_row_slabs():
+    """examples/poisson_ranks (plain C: mg_comm_unique_id / mg_comm_init / mg_dist_*): on one rank the reference script's
+    two solves with the oracle's V-cycle counts; as one rank of four rehearsed alone (a communicator of the library's own
+    making, no torch in the process) the same calls run through RCCL and report their rounds per cycle."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "poisson_ranks")
+    assert os.path.exists(exe), "build it with __graft_entry__.build() (make -C examples)"
+    n, n_para = 7, 4
+    out = subprocess.run([exe, str(n), str(n_para), "1", "0", "3"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    b0, h = main_rhs(n)
+    N = 2 ** (n + 1) + 1
+    ref = oracle.GlobalSolver(N, N, n_para, h, 50 * 0.0005)
+    ref.b[:] = b0
+    want = []
+    for _ in range(2):
+        e = ref.solve()
+        want.append((ref.it, f"{e / 50:.1e}"))
+    got = list(zip(map(int, re.findall(r"v cycles (\d+)", out.stdout)), re.findall(r"m_err/b_max=(\S+)", out.stdout)))
+    assert got == want, out.stdout
+    assert "0.0 communication rounds per cycle" in out.stdout
+    rccl = "/opt/rocm/lib/librccl.so"
+    if not os.path.exists(rccl):
+        pytest.skip("no RCCL library at " + rccl)
+    env = {k: v for k, v in os.environ.items() if k != "MG_RANKS_ID_FILE"}
+    out = subprocess.run([exe, "10", "6", "4", "2", "4"], capture_output=True, text=True, timeout=150, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"rank 2 of 4 \(rows 1024\.\.1535, (\d+) distributed levels\): 4 cycles without stop test: (\S+) ms per cycle, (\S+) "
+                  r"communication rounds per cycle, last max\|r\| (\S+)", out.stdout)
+    assert m, out.stdout
+    n_dist, ms, rounds, err = int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))
+    assert n_dist >= 1 and ms > 0 and np.isfinite(err)
+    # per distributed level two rounds, none in front of the last one's ascent pass (one level: the exchange of x and the all-gather)
+    assert rounds == (2 if n_dist == 1 else 2 * n_dist - 1)
