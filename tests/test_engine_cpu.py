@@ -214,6 +214,27 @@ def test_gloo_ranks_with_split_passes_equal_global_oracle(world, gny, gnx, n_par
         assert min(splits.values()) > 2 * 5
 
 
+# dist_levels: the caller's own choice of how many levels are cut into slabs (bench.py --dist-levels), and the cost
+# model fed with measured prices (t_round, gather_bw; bench.py times both at start-up): whatever is chosen, same values
+@pytest.mark.parametrize("kw", [dict(dist_levels=1), dict(dist_levels=2), dict(dist_levels=9), dict(t_round=1e-9, gather_bw=1e6),
+                                dict(t_round=1.0, gather_bw=1e15)], ids=str)
+def test_gloo_ranks_with_a_given_distribution_depth_equal_global_oracle(kw):
+    _gloo_run_equals_oracle(2, 257, 65, 4, True, None, **kw)
+
+
+def test_distribution_depth_follows_the_prices_it_is_given(monkeypatch):
+    from multigrid_amd.levels import choose_n_dist
+    # free rounds and a slow all-gather: cut every level that can be cut; dear rounds and a free all-gather: only the finest
+    assert choose_n_dist(8 * 32768 + 1, 32769, 11, 8, 12, t_round=1e-9, gather_bw=1e6) >= 8
+    assert choose_n_dist(8 * 32768 + 1, 32769, 11, 8, 12, t_round=1.0, gather_bw=1e15) == 1
+    monkeypatch.setenv("MG_T_ROUND_US", "1000000")
+    monkeypatch.setenv("MG_GATHER_GBPS", "1000000")
+    assert choose_n_dist(8 * 32768 + 1, 32769, 11, 8, 12) == 1
+    monkeypatch.delenv("MG_T_ROUND_US")
+    monkeypatch.delenv("MG_GATHER_GBPS")
+    assert choose_n_dist(8 * 32768 + 1, 32769, 11, 8, 12) == 6  # the defaults' choice at the bench's weak-scaling size
+
+
 def _gloo_run_equals_oracle(world, gny, gnx, n_para, fused, dist_min_rows, **kw):
     b = _rhs(gny, gnx, 7)
     h = 0.37
