@@ -1,7 +1,9 @@
 #!/bin/bash
 # One rank of an N-rank weak-scaling job rehearsed alone on one GPU (tools/rank_rehearsal.py): cycle time on one
-# rank, on a middle rank of 8 with plain copies and with RCCL in the place of the links, on rank 0 of 2, and with
-# solve()'s order of norm reads; then the kernel trace of the 8-rank case and the timeline of one of its cycles.
+# rank, on a middle rank of 8 with plain copies and with RCCL in the place of the links (the library's raw calls, and
+# through torch.distributed), on rank 0 of 2, with solve()'s order of norm reads, with the whole cycle as one graph, through
+# the C handle, and on a rank of BASELINE's 16385^2 cut into 8 slabs; then the kernel trace of the 8-rank case and the
+# timeline of one of its cycles.
 # Run on the GPU box from the repository root; results under gpurun_out/reh/.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -9,7 +11,9 @@ O=$R/gpurun_out/reh
 mkdir -p $O
 rm -rf $O/prof_w8 $O/rehearsal.txt
 cd /tmp && export TMPDIR=/tmp
-for a in "--world 1" "--world 8 --comm copy" "--world 8 --comm rccl" "--world 4 --comm rccl" "--world 2 --rank 0 --comm rccl" "--world 8 --comm rccl --solve-order" "--world 1"; do
+for a in "--world 1" "--world 8 --comm copy" "--world 8 --comm rccl" "--world 8 --comm rccl-torch" "--world 4 --comm rccl" "--world 2 --rank 0 --comm rccl" \
+         "--world 8 --comm rccl --solve-order" "--world 8 --comm rccl --engine-args {\"graph_comm\":true}" "--world 8 --native" \
+         "--world 8 --comm rccl --strong --exp 13" "--world 8 --comm rccl-torch --strong --exp 13" "--world 8 --native --strong --exp 13" "--world 1"; do
   echo "== tools/rank_rehearsal.py $a" >> $O/rehearsal.txt
   timeout -k 10 170 python3 $R/tools/rank_rehearsal.py $a 2> $O/err.txt | grep '"world"' >> $O/rehearsal.txt || { tail -20 $O/err.txt; exit 1; }
 done
