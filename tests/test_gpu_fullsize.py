@@ -281,9 +281,15 @@ def test_two_ranks_at_the_benchmark_slab_size_equal_one_rank():
 # The grids of the multi-GPU configurations cut into as many slabs as they name, every rank a process of its own
 # sharing the one GPU (gloo, messages staged through the host), values checked.
 
-def _scratch_dir():
+def _scratch_dir(need_bytes):
+    """A directory for arrays the spawned ranks read: in memory where that has the room, else under the temporary directory."""
+    import shutil
     import tempfile
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    base = None
+    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > need_bytes + (1 << 30):
+        base = "/dev/shm"
+    elif shutil.disk_usage(tempfile.gettempdir()).free < need_bytes + (1 << 30):
+        pytest.skip(f"no room for {need_bytes >> 20} MiB of arrays shared with the spawned ranks")
     return tempfile.mkdtemp(prefix="mg_slabs_", dir=base)
 
 
@@ -346,7 +352,7 @@ def test_16385_grid_in_eight_slabs_equals_oracle():
     ref = oracle.GlobalSolver(N, N, n_para, 20.0 / 2 ** (n + 1), 0.0)
     ref.b[:] = b
     ref.solve(ncycles=cycles)
-    ddir = _scratch_dir()
+    ddir = _scratch_dir(3 * b.nbytes)
     try:
         np.save(os.path.join(ddir, "b.npy"), b)
         np.save(os.path.join(ddir, "x.npy"), ref.x)
@@ -373,7 +379,7 @@ def test_32769_grid_in_slabs_equals_one_rank(world):
     from tests.mp_util import run_ranks
     n, n_para, cycles = 14, 10, 2
     one = _engine(n, n_para, eager_dead_levels=True)
-    ddir = _scratch_dir()
+    ddir = _scratch_dir(one.plan.gnx ** 2 * 8)
     try:
         brows = one.local_rows(one.b0)
         N = one.plan.gnx
