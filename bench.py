@@ -27,6 +27,12 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 (profiles/traffic.json, measured on tools/pmc_probe.py; printed only when the kernel sources
                 are the ones it was measured on).  The plain Jacobi sweep (24 B per point) is beside it.
   cycle         the same two prices for the whole V-cycle
+  host_issue_ms_per_cycle, per_rank   host time to enqueue one cycle (clock stopped before the device is waited for), and every
+                rank's own record gathered to rank 0: its ms per step, host issue time, finest pass and Jacobi sweep ms,
+                communication rounds per cycle, passes cut around their exchange, communication mode
+  config.comm   N > 1: how the rows travel ("native" = raw RCCL groups issued by libmg_hip.so on the engine's streams) and
+                the exchange round and all-gather timed at start-up, from which the number of distributed levels was chosen
+  pcie          host <-> device copy of one finest-level array, measured after the timed region (never part of `value`)
   cpu_baseline  the CPU oracle (C restatement of the reference algorithm) timed on this host's cores on a
                 bounded sample: the undecomposed schedule with OpenMP row-parallel sweeps on all cores, and
                 the reference's own decomposition -- four 2 x 2 blocks, one thread per block, an exchange per
