@@ -72,7 +72,7 @@ def test_default_engine_selects_its_placement_at_32769():
     matter (>= 1 GiB each): the finest pass on the chosen arrays is of the fast kind, and set-up stays short."""
     e = _engine(14, 10, eager_dead_levels=True)
     assert e.placement is not None and e.placement["candidates"] >= 4 and e.placement_seconds < 10
-    assert e.placement["ms_chosen_combination"] <= 1.03 * min(e.placement["ms_as_output"])
+    assert e.placement["ms_chosen_combination"] <= 1.06 * min(e.placement["ms_as_output"])  # the two kinds are 10 % and more apart
     e.close()
     small = _engine(10, 6)
     assert small.placement is None
